@@ -1,0 +1,220 @@
+/*
+ * mimeo_hip.h — C-ABI of libmimeo_hip.so, the MI355X (gfx950) engine behind the
+ * `mimeo self | x | map` hot path.
+ *
+ * What this boundary replaces in the reference (Adamtaranto/mimeo):
+ *   the reference has no library API for its hot path; it builds a shell script
+ *   (src/mimeo/wrappers.py:899-1271 self_LZ_cmds, :683-896 xspecies_LZ_cmds,
+ *   :525-680 map_LZ_cmds) and runs it with src/mimeo/utils.py:213-254 run_cmd.
+ *   Every entry point below cites the command line(s) of that script whose work
+ *   it performs.  The Python host (mimeo_amd/) binds these with ctypes; see
+ *   INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross the boundary;
+ *   - every function returns 0 on success, <0 on error; the message is read with
+ *     mimeo_last_error() (reference convention: non-zero exit of run_jobs.sh ->
+ *     RuntimeError, utils.py:194-210);
+ *   - buffers returned through `**out` are allocated by the library and released
+ *     with mimeo_free(); inputs are borrowed for the duration of the call;
+ *   - calls are blocking; a handle must not be used from two threads at once;
+ *   - coordinates are 0-based half-open inside the ABI.  The origin-one `start1`
+ *     / `start2+` columns of LASTZ's `general` format (wrappers.py:1031) are
+ *     produced by the host writer, not here.
+ *   - there is NO CPU fallback: every entry point that computes fails with
+ *     MIMEO_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MIMEO_HIP_H
+#define MIMEO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMEO_ABI_VERSION 1
+
+enum {
+    MIMEO_OK = 0,
+    MIMEO_ERR_ARG = -1,        /* bad argument (null pointer, id out of range, ...) */
+    MIMEO_ERR_NO_DEVICE = -2,  /* no usable HIP device / library not initialised   */
+    MIMEO_ERR_HIP = -3,        /* a HIP runtime call failed                         */
+    MIMEO_ERR_NOMEM = -4,      /* host or device allocation failed                  */
+    MIMEO_ERR_LIMIT = -5       /* input exceeds a documented limit                  */
+};
+
+/* Strand selector == lastz --strand=plus|minus|both (wrappers.py:1031 passes both). */
+enum { MIMEO_STRAND_PLUS = 1, MIMEO_STRAND_MINUS = 2, MIMEO_STRAND_BOTH = 3 };
+
+/*
+ * Alignment parameters == the lastz flags the reference passes
+ * (wrappers.py:1025-1037 / 786-798 / 607-653) plus the LASTZ defaults they imply.
+ * mimeo_params_default() fills the values in brackets.
+ */
+typedef struct mimeo_params {
+    int32_t hspthresh;    /* --hspthresh [3000]; also the gapped threshold (lastz default)  */
+    int32_t xdrop;        /* ungapped x-drop [910 = 10*sub[A][A]]                          */
+    int32_t ydrop;        /* gapped y-drop [9400 = open + 300*extend]                      */
+    int32_t gap_open;     /* [400]                                                        */
+    int32_t gap_extend;   /* [30]                                                         */
+    int32_t transitions;  /* seed tolerates one transition [1] (lastz default)            */
+    int32_t entropy;      /* --entropy [1]                                                */
+    int32_t chain;        /* --chain [1]                                                  */
+    int32_t gapped;       /* --gapped [1]                                                 */
+    int32_t strand;       /* --strand [MIMEO_STRAND_BOTH]                                 */
+    int32_t reserved[6];
+} mimeo_params;
+
+/* One raw seed hit: 0-based starts of the 19-base seed window (12of19, lastz default seed). */
+typedef struct mimeo_seed_hit {
+    uint32_t tpos;
+    uint32_t qpos; /* on the strand being scanned (reverse-complement coordinates for '-') */
+} mimeo_seed_hit;
+
+/* One gap-free HSP (lastz --gfextend output, after --entropy and --hspthresh). */
+typedef struct mimeo_hsp {
+    uint32_t tstart;
+    uint32_t qstart; /* strand coordinates, as above */
+    uint32_t length;
+    uint32_t flags;  /* bit0: survives --chain (set by mimeo_chain_hsps / align) */
+    int64_t score;   /* entropy-adjusted score (== raw when entropy is off) */
+    int64_t raw_score;
+} mimeo_hsp;
+
+/*
+ * One gapped alignment == one row of lastz --format=general:name1,strand1,start1,
+ * end1,length1,name2,strand2,start2+,end2+,length2,score,identity (wrappers.py:1031).
+ * qstart/qend are on the query PLUS strand (like start2+/end2+), 0-based half-open.
+ */
+typedef struct mimeo_alignment {
+    uint32_t tid;    /* index of the target scaffold in genome A */
+    uint32_t qid;    /* index of the query scaffold in genome B (or A for self) */
+    uint32_t tstart, tend;
+    uint32_t qstart, qend;
+    int64_t score;
+    uint32_t id_n;   /* identity numerator: matched columns                         */
+    uint32_t id_d;   /* identity denominator: matched + mismatched columns (no gaps) */
+    uint32_t qstrand; /* 0 '+', 1 '-' */
+    uint32_t reserved;
+} mimeo_alignment;
+
+/* Half-open interval on a chromosome, BED-interpreted (wrappers.py:1120). */
+typedef struct mimeo_interval {
+    uint32_t chrom;
+    uint32_t start;
+    uint32_t end;
+} mimeo_interval;
+
+/* Per-call statistics of the last mimeo_align_pairs / stage call (metrics). */
+typedef struct mimeo_stats {
+    uint64_t pair_strands;        /* (target, query, strand) units processed              */
+    uint64_t seed_hits;           /* raw seed hits produced by the seed-scan kernel        */
+    uint64_t hsps;                /* HSPs >= hspthresh                                    */
+    uint64_t chained_hsps;
+    uint64_t alignments;
+    uint64_t query_bases_scanned; /* sum over pair-strands of Lq                           */
+    uint64_t scan_bytes_algorithmic; /* SURVEY §8(d) B_scan summed over pair-strands       */
+    uint64_t scan_bytes_kernel;   /* compulsory bytes of the index-join kernel  */
+    double ms_index;              /* HIP-event time in the index-build kernels              */
+    double ms_scan;               /* HIP-event time in the seed-scan (count+fill) kernels   */
+    double ms_extend;             /* ungapped extension + resolution                       */
+    double ms_chain;
+    double ms_gapped;
+    double ms_collapse;
+    double ms_total;              /* host wall time of the call                            */
+    uint64_t scan_launches;       /* number of seed-scan fill launches timed in ms_scan_fill */
+    double ms_scan_fill;          /* HIP-event time of the fill kernel alone (the roofline kernel) */
+    uint64_t reserved[6];
+} mimeo_stats;
+
+typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+
+/* ABI version of the loaded library (compare with MIMEO_ABI_VERSION). Never fails. */
+int mimeo_abi_version(void);
+
+/* Select HIP device `device` for this process and create the library's streams.
+ * One process drives one GPU (multi-GPU = one process per GPU). */
+int mimeo_init(int device);
+void mimeo_shutdown(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *mimeo_last_error(void);
+
+/* Fill *p with the LASTZ defaults listed at mimeo_params. */
+int mimeo_params_default(mimeo_params *p);
+
+int mimeo_get_stats(mimeo_stats *out);
+
+void mimeo_free(void *p);
+
+/* ---- genome ingest (replaces utils.py:274-309 splitFasta + lastz's own file read) --- */
+
+/*
+ * Upload `nscaf` scaffolds given as concatenated ASCII bases (`bases`, any case,
+ * anything outside ACGTacgt is treated as N) with `offsets[nscaf+1]` delimiting
+ * them, and pack them on the device into 2-bit bit-planes + N / soft-mask planes
+ * for both strands (kernel K1).  Lower-case target bases are excluded from seeding
+ * and N from seeding on both sides, as lastz does by default.
+ */
+int mimeo_genome_create(uint32_t nscaf, const uint8_t *bases, const uint64_t *offsets,
+                        mimeo_genome **out);
+void mimeo_genome_destroy(mimeo_genome *g);
+int mimeo_genome_nscaf(const mimeo_genome *g, uint32_t *nscaf);
+int mimeo_genome_length(const mimeo_genome *g, uint32_t scaf, uint64_t *length);
+
+/* ---- stage entry points (parity tests, profiling) ----------------------------- */
+
+/*
+ * lastz seed stage (SURVEY §8a A6+A7): build the 12of19 seed index of target
+ * scaffold `tid` of T and of query scaffold `qid` of Q on strand `qstrand`
+ * (0 '+', 1 '-'), and return every seed hit.  Order of the returned hits is
+ * unspecified; the multiset is exact.
+ */
+int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid,
+                    uint32_t qstrand, const mimeo_params *p, mimeo_seed_hit **out, uint64_t *nout);
+
+/*
+ * lastz --gfextend --entropy --hspthresh (A8): seed hits -> gap-free HSPs with the
+ * per-diagonal "already extended" suppression.  Returned sorted by
+ * (tstart-qstart, tstart).
+ */
+int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid,
+                        uint32_t qstrand, const mimeo_params *p, mimeo_hsp **out, uint64_t *nout);
+
+/*
+ * One full `lastz t.fa q.fa ...` invocation (A6-A10; wrappers.py:1025-1037): all
+ * requested strands of one (target, query) pair -> gapped alignments.
+ */
+int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid,
+                     const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
+
+/* ---- whole-job entry points ---------------------------------------------------- */
+
+/*
+ * The per-pair loop of run_jobs.sh (wrappers.py:1015-1059): for k in [0,npairs)
+ * align target scaffold pair_t[k] of A against query scaffold pair_q[k] of B
+ * (B == NULL: of A, i.e. `mimeo self`).  Results are concatenated in pair order;
+ * the host applies the awk/sort filter (A11) when it writes the TAB.
+ */
+int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t,
+                      const uint32_t *pair_q, uint64_t npairs, const mimeo_params *p,
+                      mimeo_alignment **out, uint64_t *nout);
+
+/*
+ * bedtools genomecov -bg | awk $4>=min_cov | sort | bedtools merge | awk len>=min_len
+ * (A13+A14; wrappers.py:1131-1177) as one integer kernel pipeline (K7).  Intervals
+ * with start >= end are ignored, ends are clipped to chrom_len[chrom].  Output is
+ * sorted by (chrom, start).
+ */
+int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t *chrom_len,
+                            uint32_t nchrom, uint32_t min_cov, uint32_t min_len,
+                            mimeo_interval **out, uint64_t *nout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMEO_HIP_H */

@@ -1,0 +1,137 @@
+"""Pure-Python restatement of the integer / text half of mimeo's hot path (stages A11-A16).
+
+TEST INFRASTRUCTURE ONLY (see oracle/mimeo_oracle.c header).  Unlike the alignment half this
+part IS pinned: tests/test_oracle_golden.py checks every function here against vectors made by
+running the reference's own command text / pandas code (tests/golden/make_golden.py).
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+"""
+import numpy as np
+
+
+def general_rows(names_t, names_q, lens_q, alns):
+    """lastz --format=general:name1,strand1,start1,end1,length1,name2,strand2,start2+,end2+,
+    length2,score,identity rows (src/mimeo/wrappers.py:1031) from oracle/engine alignment
+    records (0-based half-open, query on the plus strand).  start1/start2+ are origin-one,
+    the identity field expands to 'n/d' and 'pct%' (SURVEY §8a A10)."""
+    rows = []
+    for a in alns:
+        n, d = int(a['id_n']), int(a['id_d'])
+        pct = '%.1f%%' % (100.0 * n / d) if d else '0.0%'
+        rows.append('\t'.join(map(str, [
+            names_t[int(a['tid'])], '+', int(a['tstart']) + 1, int(a['tend']),
+            int(a['tend']) - int(a['tstart']),
+            names_q[int(a['qid'])], '-' if int(a['qstrand']) else '+', int(a['qstart']) + 1, int(a['qend']),
+            int(a['qend']) - int(a['qstart']), int(a['score']), '%d/%d' % (n, d), pct])))
+    return rows
+
+
+def _awk_num(s):
+    """awk's ``0+$n``: longest numeric prefix, 0 if none."""
+    import re
+    m = re.match(r'\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)', s)
+    return float(m.group(0)) if m else 0.0
+
+
+def _sort_key_tab(line, numfield):
+    f = line.split()
+    return (f[0].encode(), _awk_num(f[numfield]), line.encode())
+
+
+def filter_project_sort(general_text, min_len, min_idt):
+    """wrappers.py:1040-1056: sed 's/%//g' ; awk '!/^#/' | awk '0+$5>=minLen' |
+    awk -v OFS='\\t' '0+$13>=minIdt {print $1,$2,$3,$4,$6,$7,$8,$9,$11,$13}' | sed 's/ //g' |
+    sort -k 1,1 -k 3n,4n   (C locale; last-resort whole-line byte order)."""
+    out = []
+    for line in general_text.replace('%', '').split('\n'):
+        if not line or line.startswith('#'):
+            continue
+        f = line.split()
+        if len(f) < 13:
+            continue
+        if _awk_num(f[4]) >= min_len and _awk_num(f[12]) >= min_idt:
+            out.append('\t'.join([f[0], f[1], f[2], f[3], f[5], f[6], f[7], f[8], f[10], f[12]]).replace(' ', ''))
+    out.sort(key=lambda l: _sort_key_tab(l, 2))
+    return out
+
+
+def bed_project_sort(tab_lines):
+    """wrappers.py:1120-1128: awk '!/^#/ {print $1,$3,$4}' | sed 's/%//g' | sort -k 1,1 -k 2n,3n."""
+    bed = []
+    for line in tab_lines:
+        if not line or line.startswith('#'):
+            continue
+        f = line.split()
+        bed.append('\t'.join([f[0], f[2], f[3]]).replace('%', ''))
+    bed.sort(key=lambda l: _sort_key_tab(l, 1))
+    return bed
+
+
+def coverage_collapse(intervals, chromlens, min_cov, min_len):
+    """wrappers.py:1131-1150 + :1166-1167: bedtools genomecov -bg -g lens | awk '$4>=cov' | sort |
+    bedtools merge | awk '$3-$2>=minLen', restated per base: depth[x] = number of half-open
+    [start,end) intervals covering x (ends clipped to the chromosome length); keep maximal runs
+    of depth >= min_cov (book-ended runs merge, bedtools merge -d 0) of length >= min_len.
+    ``intervals`` = iterable of (chrom, start, end); ``chromlens`` = dict chrom -> length.
+    Returns [(chrom, start, end)] sorted by (chrom bytes, start)."""
+    per = {}
+    for c, s, e in intervals:
+        per.setdefault(c, []).append((int(s), int(e)))
+    out = []
+    for c in sorted(per, key=lambda x: x.encode() if isinstance(x, str) else x):
+        L = int(chromlens[c])
+        diff = np.zeros(L + 1, dtype=np.int64)
+        for s, e in per[c]:
+            e = min(e, L)
+            if s >= e:
+                continue
+            diff[s] += 1
+            diff[e] -= 1
+        depth = np.cumsum(diff[:L])
+        mask = depth >= max(1, min_cov)
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], mask.view(np.int8), [0]))))
+        for s, e in zip(edges[0::2], edges[1::2]):
+            if e - s >= min_len:
+                out.append((c, int(s), int(e)))
+    return out
+
+
+def gff_self_lines(regions, label, prefix, source='mimeo-self'):
+    """wrappers.py:1153-1177 (x: :870-894, source 'mimeo'): header + one row per region, ID counter
+    in output order, start written un-shifted."""
+    lines = ['##gff-version 3', '#seqid\tsource\ttype\tstart\tend\tscore\tstrand\tphase\tattributes']
+    for i, (c, s, e) in enumerate(regions, 1):
+        lines.append('\t'.join([str(c), source, label, str(s), str(e), '.', '+', '.', 'ID=%s_%05d' % (prefix, i)]))
+    return lines
+
+
+def import_align(tab_text, prefix, min_len, min_idt):
+    """wrappers.py:33-117 import_Align: re-filter int(end)-int(start) >= minLen and float(pID) >=
+    minIdt, sort by the STRING columns (tName, tStart, tEnd, tStrand) — lexicographic, stable —
+    then UID = prefix_<rank zero-padded to len(str(n))>."""
+    hits = []
+    for line in tab_text.split('\n'):
+        li = line.strip()
+        if not li or li.startswith('#'):
+            continue
+        f = li.split()
+        if int(f[3]) - int(f[2]) >= min_len and float(f[9]) >= min_idt:
+            hits.append(f[:10])
+    order = sorted(range(len(hits)), key=lambda k: (hits[k][0], hits[k][2], hits[k][3], hits[k][1]))
+    width = len(str(len(hits)))
+    out = []
+    for rank, k in enumerate(order, 1):
+        out.append(hits[k] + ['%s_%s' % (prefix if prefix else 'BHit', str(rank).zfill(width))])
+    return out
+
+
+def gff_map_lines(rows, chromlens, ftype='BHit'):
+    """wrappers.py:443-522 writeGFFlines."""
+    lines = ['##gff-version 3']
+    for name, ln in chromlens or []:
+        lines.append(' '.join(['##sequence-region', str(name), '1', str(ln)]))
+    lines.append('\t'.join(['##seqid', 'source', 'type', 'start', 'end', 'score', 'strand', 'phase', 'attributes']))
+    for r in rows:
+        attrs = ';'.join(['ID=' + r[10], 'identity=' + str(r[9]), 'B_locus=' + '_'.join([r[4], r[5], r[6], r[7]])])
+        lines.append('\t'.join([r[0], 'mimeo-map', ftype, r[2], r[3], r[8], r[1], '.', attrs]))
+    return lines
