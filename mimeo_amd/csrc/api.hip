@@ -1,0 +1,184 @@
+// api.hip — the C-ABI of libmimeo_hip.so (include/mimeo_hip.h).  Host-side runtime only:
+// device selection, streams, error strings, genome handles, stage orchestration.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace mimeo {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static bool g_init = false;
+static int g_device = -1;
+mimeo_stats g_stats;
+
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_err = buf;
+    return MIMEO_ERR_HIP;
+}
+hipStream_t stream() { return g_stream; }
+bool initialised() { return g_init; }
+
+static int need_init() {
+    if (!g_init) {
+        set_error("mimeo_init() has not been called or no gfx950 device is available (no CPU fallback exists)");
+        return MIMEO_ERR_NO_DEVICE;
+    }
+    return 0;
+}
+
+}  // namespace mimeo
+
+using namespace mimeo;
+
+extern "C" {
+
+int mimeo_abi_version(void) { return MIMEO_ABI_VERSION; }
+
+const char *mimeo_last_error(void) { return g_err.c_str(); }
+
+int mimeo_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: the mimeo engine has no CPU fallback");
+        return MIMEO_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device index out of range"); return MIMEO_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return MIMEO_ERR_NO_DEVICE;
+    }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_init = true;
+    memset(&g_stats, 0, sizeof g_stats);
+    return MIMEO_OK;
+}
+
+void mimeo_shutdown(void) {
+    if (g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    g_init = false;
+}
+
+int mimeo_params_default(mimeo_params *p) {
+    if (!p) { set_error("null params"); return MIMEO_ERR_ARG; }
+    memset(p, 0, sizeof *p);
+    p->hspthresh = 3000; p->xdrop = 910; p->ydrop = 9400; p->gap_open = 400; p->gap_extend = 30;
+    p->transitions = 1; p->entropy = 1; p->chain = 1; p->gapped = 1; p->strand = MIMEO_STRAND_BOTH;
+    return MIMEO_OK;
+}
+
+int mimeo_get_stats(mimeo_stats *out) {
+    if (!out) { set_error("null stats"); return MIMEO_ERR_ARG; }
+    *out = g_stats;
+    return MIMEO_OK;
+}
+
+void mimeo_free(void *p) { free(p); }
+
+int mimeo_genome_create(uint32_t nscaf, const uint8_t *bases, const uint64_t *offsets, mimeo_genome **out) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!out || !offsets || (!bases && nscaf && offsets[nscaf] > 0)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    mimeo_genome *g = new mimeo_genome();
+    g->scaf.resize(nscaf);
+    uint64_t maxlen = 0;
+    for (uint32_t i = 0; i < nscaf; i++) {
+        if (offsets[i + 1] < offsets[i]) { delete g; set_error("offsets not monotone"); return MIMEO_ERR_ARG; }
+        maxlen = std::max<uint64_t>(maxlen, offsets[i + 1] - offsets[i]);
+    }
+    uint8_t *d_ascii = nullptr;
+    hipError_t e = hipMalloc((void **)&d_ascii, maxlen ? maxlen : 1);
+    if (e != hipSuccess) { delete g; return hip_fail(e, "hipMalloc(ascii)", __FILE__, __LINE__); }
+    for (uint32_t i = 0; i < nscaf && !rc; i++) {
+        uint64_t len = offsets[i + 1] - offsets[i];
+        if (len) {
+            e = hipMemcpyAsync(d_ascii, bases + offsets[i], len, hipMemcpyHostToDevice, stream());
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpy(ascii)", __FILE__, __LINE__); break; }
+        }
+        rc = pack_scaffold(d_ascii, len, g->scaf[i]);
+    }
+    (void)hipStreamSynchronize(stream());
+    (void)hipFree(d_ascii);
+    if (rc) { mimeo_genome_destroy(g); return rc; }
+    *out = g;
+    return MIMEO_OK;
+}
+
+void mimeo_genome_destroy(mimeo_genome *g) {
+    if (!g) return;
+    for (auto &s : g->scaf) free_scaffold(s);
+    delete g;
+}
+
+int mimeo_genome_nscaf(const mimeo_genome *g, uint32_t *nscaf) {
+    if (!g || !nscaf) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    *nscaf = (uint32_t)g->scaf.size();
+    return MIMEO_OK;
+}
+
+int mimeo_genome_length(const mimeo_genome *g, uint32_t scaf, uint64_t *length) {
+    if (!g || !length || scaf >= g->scaf.size()) { set_error("bad scaffold id"); return MIMEO_ERR_ARG; }
+    *length = g->scaf[scaf].len;
+    return MIMEO_OK;
+}
+
+static int check_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, const void *p,
+                      const void *out, const void *nout) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!T || !Q || !p || !out || !nout) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    if (tid >= T->scaf.size() || qid >= Q->scaf.size()) { set_error("scaffold id out of range"); return MIMEO_ERR_ARG; }
+    return 0;
+}
+
+int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, uint32_t qstrand,
+                    const mimeo_params *p, mimeo_seed_hit **out, uint64_t *nout) {
+    int rc = check_pair(T, tid, Q, qid, p, out, nout);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g_stats, 0, sizeof g_stats);
+    const Scaffold &ts = T->scaf[tid], &qs = Q->scaf[qid];
+    SeedIndex it, iq;
+    float ms_index = 0;
+    if ((rc = build_index(ts.fwd.view(true), it, &ms_index))) return rc;
+    if ((rc = build_index((qstrand ? qs.rc : qs.fwd).view(false), iq, &ms_index))) { it.release(); return rc; }
+    DeviceBuf hits;
+    uint64_t n = 0;
+    JoinTiming tm;
+    rc = join_hits(it.view(), iq.view(), p->transitions, hits, &n, &tm);
+    if (!rc) {
+        mimeo_seed_hit *h = (mimeo_seed_hit *)malloc((n ? n : 1) * sizeof(mimeo_seed_hit));
+        if (!h) { set_error("host allocation failed"); rc = MIMEO_ERR_NOMEM; }
+        else {
+            hipError_t e = hipSuccess;
+            if (n) e = hipMemcpy(h, hits.p, n * sizeof(mimeo_seed_hit), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { free(h); rc = hip_fail(e, "hipMemcpy(hits)", __FILE__, __LINE__); }
+            else { *out = h; *nout = n; }
+        }
+    }
+    hits.release();
+    it.release();
+    iq.release();
+    g_stats.pair_strands = 1;
+    g_stats.seed_hits = n;
+    g_stats.query_bases_scanned = qs.len;
+    g_stats.ms_index = ms_index;
+    g_stats.ms_scan = tm.ms_count + tm.ms_fill;
+    g_stats.ms_scan_fill = tm.ms_fill;
+    g_stats.scan_launches = 1;
+    g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+}  // extern "C"

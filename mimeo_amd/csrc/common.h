@@ -1,0 +1,109 @@
+// common.h — shared declarations of the mimeo HIP engine (gfx950 only).
+//
+// Data layout in HBM:
+//   a scaffold strand is stored as 1-bit planes, one u32 word per 32 bases, base i at bit
+//   (i & 31) of word (i >> 5):
+//     lo  — bit 0 of the 2-bit code (A0 C1 G2 T3)
+//     hi  — bit 1 of the 2-bit code; a transition (A<->G, C<->T) flips exactly this bit
+//     nm  — 1 where the base is not ACGT (scored as N)
+//     sv  — 1 where a valid 12of19 seed word starts (no N, and for the target no lower case,
+//           inside the 19-base window, and the window fits)
+//   Every plane has PLANE_PAD zero words in front of word 0 and behind the last word so that
+//   window loads never need a bounds check.
+//   The seed index of a strand is CSR: off[2^24 + 1] (u32) and pos[nvalid] (u32, ascending
+//   inside a bucket).  Key = (pext12(lo window) << 12) | pext12(hi window): the low 12 bits are
+//   the transition bits, so the 13 words within one transition of a key differ only in the low
+//   12 bits and a block of 4096 consecutive keys ("tile") is closed under them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mimeo_hip.h"
+
+namespace mimeo {
+
+constexpr int SEED_LEN = 19;
+constexpr int SEED_WEIGHT = 12;
+constexpr uint32_t NBUCKET = 1u << 24;
+constexpr uint32_t TILE_WORDS = 4096;  // keys per join tile
+constexpr uint32_t NTILE = NBUCKET / TILE_WORDS;
+constexpr int PLANE_PAD = 8;  // u32 words (256 bases) of zero padding on both sides
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define HIP_TRY(call)                                                         \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return mimeo::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// device views ---------------------------------------------------------------------------
+struct StrandView {
+    const uint32_t *lo, *hi, *nm, *sv;  // pointers to word 0 (padding lies before/after)
+    uint32_t len;                        // bases
+};
+
+struct IndexView {
+    const uint32_t *off;  // NBUCKET + 1
+    const uint32_t *pos;
+    uint32_t n;  // number of indexed positions
+};
+
+// host-side owner of one strand's planes
+struct Strand {
+    uint32_t *base = nullptr;  // one allocation: lo | hi | nm | sv (each nwords + 2*PLANE_PAD)
+    uint32_t *sv_target = nullptr;  // separate sv plane for the target role (soft-mask aware); null = same as sv
+    uint32_t nwords = 0;
+    uint32_t len = 0;
+    StrandView view(bool as_target) const;
+};
+
+struct SeedIndex {
+    uint32_t *off = nullptr;
+    uint32_t *pos = nullptr;
+    uint32_t n = 0;
+    IndexView view() const { return IndexView{off, pos, n}; }
+    void release();
+};
+
+struct Scaffold {
+    uint64_t len = 0;
+    bool has_lower = false;
+    Strand fwd, rc;
+};
+
+}  // namespace mimeo
+
+struct mimeo_genome {
+    std::vector<mimeo::Scaffold> scaf;
+};
+
+namespace mimeo {
+
+// stream used by every kernel launch of the library (created by mimeo_init)
+hipStream_t stream();
+bool initialised();
+
+// K1: ASCII -> planes for both strands (k1_pack.hip)
+int pack_scaffold(const uint8_t *d_ascii, uint64_t len, Scaffold &out);
+void free_scaffold(Scaffold &s);
+
+// K2: seed index of one strand (k2_index.hip)
+int build_index(const StrandView &s, SeedIndex &out, float *ms);
+
+// K3: index join (k3_join.hip).  Produces all seed hits of (T, Q) into a device buffer the
+// caller owns (grown on demand).
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+struct JoinTiming { float ms_count = 0, ms_fill = 0; };
+int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
+              JoinTiming *tm);
+
+}  // namespace mimeo

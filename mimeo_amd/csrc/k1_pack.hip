@@ -1,0 +1,140 @@
+// K1 — ASCII scaffold -> bit planes for both strands, and seed-start validity planes.
+// Replaces the sequence loading lastz does for `lastz T Q` (reference call site
+// src/mimeo/wrappers.py:1025-1031) and the per-scaffold split of utils.py:274-309.
+// Runs once per genome; not on the timed path.
+#include "common.h"
+
+namespace mimeo {
+
+// one thread per output word (32 bases)
+__global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, int reverse,
+                               uint32_t *__restrict__ lo, uint32_t *__restrict__ hi,
+                               uint32_t *__restrict__ nm, uint32_t *__restrict__ lower,
+                               uint32_t nwords, uint32_t *__restrict__ any_lower) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t vlo = 0, vhi = 0, vnm = 0, vlow = 0;
+    uint32_t base = w * 32u;
+#pragma unroll 4
+    for (uint32_t b = 0; b < 32; b++) {
+        uint32_t i = base + b;
+        if (i >= len) break;
+        uint8_t c = reverse ? ascii[len - 1 - i] : ascii[i];
+        uint32_t low = (c >= 'a' && c <= 'z');
+        if (low) c -= 32;
+        uint32_t code = 4;
+        if (c == 'A') code = 0;
+        else if (c == 'C') code = 1;
+        else if (c == 'G') code = 2;
+        else if (c == 'T') code = 3;
+        if (code == 4) {
+            vnm |= 1u << b;
+        } else {
+            if (reverse) code = 3 - code;
+            vlo |= (code & 1u) << b;
+            vhi |= (code >> 1) << b;
+        }
+        vlow |= low << b;
+    }
+    lo[w] = vlo;
+    hi[w] = vhi;
+    nm[w] = vnm;
+    if (lower) {
+        lower[w] = vlow;
+        if (vlow) atomicOr(any_lower, 1u);
+    }
+}
+
+// sv bit p = 1 iff p + 19 <= len and no bad base in [p, p+19); bad = nm | lower (lower may be null)
+__global__ void k1_seed_valid(const uint32_t *__restrict__ nm, const uint32_t *__restrict__ lower,
+                              uint32_t len, uint32_t nwords, uint32_t *__restrict__ sv) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t bad = (uint64_t)nm[w] | ((uint64_t)nm[w + 1] << 32);  // word nwords is padding (zero)
+    if (lower) bad |= (uint64_t)lower[w] | ((uint64_t)lower[w + 1] << 32);
+    uint64_t b1 = bad | (bad >> 1);
+    uint64_t b2 = b1 | (b1 >> 2);
+    uint64_t b4 = b2 | (b2 >> 4);
+    uint64_t b8 = b4 | (b4 >> 8);                      // offsets 0..15
+    uint64_t inv = b8 | (b1 >> 16) | (bad >> 18);      // + 16,17 + 18
+    uint32_t ok = ~(uint32_t)inv;
+    // range: p + 19 <= len
+    uint32_t base = w * 32u;
+    if (len < SEED_LEN || base > len - SEED_LEN) ok = 0;
+    else {
+        uint32_t lastp = len - SEED_LEN;  // inclusive
+        if (lastp - base < 31) ok &= (2u << (lastp - base)) - 1u;
+    }
+    sv[w] = ok;
+}
+
+static int alloc_strand(Strand &s, uint32_t len) {
+    s.len = len;
+    s.nwords = (len + 31) / 32;
+    size_t per = (size_t)s.nwords + 2 * PLANE_PAD;
+    HIP_TRY(hipMalloc((void **)&s.base, per * 4 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(s.base, 0, per * 4 * sizeof(uint32_t), stream()));
+    return 0;
+}
+
+StrandView Strand::view(bool as_target) const {
+    size_t per = (size_t)nwords + 2 * PLANE_PAD;
+    StrandView v;
+    v.lo = base + PLANE_PAD;
+    v.hi = base + per + PLANE_PAD;
+    v.nm = base + 2 * per + PLANE_PAD;
+    v.sv = (as_target && sv_target) ? sv_target + PLANE_PAD : base + 3 * per + PLANE_PAD;
+    v.len = len;
+    return v;
+}
+
+int pack_scaffold(const uint8_t *d_ascii, uint64_t len64, Scaffold &out) {
+    if (len64 > 0xFFFFFF00ull) { set_error("scaffold longer than 2^32-256 bases"); return MIMEO_ERR_LIMIT; }
+    uint32_t len = (uint32_t)len64;
+    out.len = len64;
+    int rc;
+    if ((rc = alloc_strand(out.fwd, len))) return rc;
+    if ((rc = alloc_strand(out.rc, len))) return rc;
+    uint32_t nwords = out.fwd.nwords;
+    if (nwords == 0) return 0;
+    size_t per = (size_t)nwords + 2 * PLANE_PAD;
+    uint32_t *d_lower = nullptr, *d_flag = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_lower, per * sizeof(uint32_t) + 64));
+    HIP_TRY(hipMemsetAsync(d_lower, 0, per * sizeof(uint32_t) + 64, stream()));
+    d_flag = d_lower + per;
+    dim3 blk(256), grd((nwords + 255) / 256);
+    StrandView f = out.fwd.view(false), r = out.rc.view(false);
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 0, (uint32_t *)f.lo, (uint32_t *)f.hi,
+                       (uint32_t *)f.nm, d_lower + PLANE_PAD, nwords, d_flag);
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 1, (uint32_t *)r.lo, (uint32_t *)r.hi,
+                       (uint32_t *)r.nm, (uint32_t *)nullptr, nwords, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f.nm, (const uint32_t *)nullptr, len, nwords,
+                       (uint32_t *)f.sv);
+    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), r.nm, (const uint32_t *)nullptr, len, nwords,
+                       (uint32_t *)r.sv);
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    out.has_lower = flag != 0;
+    if (out.has_lower) {
+        // the target role excludes soft-masked (lower-case) bases from seeding: separate sv plane
+        HIP_TRY(hipMalloc((void **)&out.fwd.sv_target, per * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(out.fwd.sv_target, 0, per * sizeof(uint32_t), stream()));
+        hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f.nm, (const uint32_t *)(d_lower + PLANE_PAD), len,
+                           nwords, out.fwd.sv_target + PLANE_PAD);
+        HIP_TRY(hipStreamSynchronize(stream()));
+    }
+    HIP_TRY(hipFree(d_lower));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+void free_scaffold(Scaffold &s) {
+    if (s.fwd.base) (void)hipFree(s.fwd.base);
+    if (s.fwd.sv_target) (void)hipFree(s.fwd.sv_target);
+    if (s.rc.base) (void)hipFree(s.rc.base);
+    s.fwd = Strand();
+    s.rc = Strand();
+}
+
+}  // namespace mimeo

@@ -1,0 +1,112 @@
+// K2 — 12of19 seed index of one scaffold strand (lastz's target seed-word
+// position table, --step=1; reference call site src/mimeo/wrappers.py:1028-1031).
+//
+// Layout: CSR  off[2^24+1], pos[n]  keyed by  (pext12(lo) << 12) | pext12(hi)  (common.h).
+// Built once per scaffold strand and reused against every partner scaffold — the reference
+// rebuilds lastz's table in each of its S^2 invocations.
+//
+// The (key,pos) ordering uses rocPRIM's device radix sort: this is plumbing executed 2*S times
+// per job against S^2*2 seed scans, not a hot kernel.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace mimeo {
+
+// 12 care bits of the 19-bit window: offsets {0,1,2,4,7,8,11,13,15,16,17,18}
+__device__ __forceinline__ uint32_t pext12(uint32_t x) {
+    return (x & 0x7u) | ((x >> 1) & 0x8u) | ((x >> 3) & 0x30u) | ((x >> 5) & 0x40u) | ((x >> 6) & 0x80u) |
+           ((x >> 7) & 0xF00u);
+}
+
+// one thread per 32 start positions: keys (1<<24 for "no seed here") + histogram
+__global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict__ keys,
+                             uint32_t *__restrict__ posv, uint32_t *__restrict__ hist) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t lo = (uint64_t)s.lo[w] | ((uint64_t)s.lo[w + 1] << 32);
+    uint64_t hi = (uint64_t)s.hi[w] | ((uint64_t)s.hi[w + 1] << 32);
+    uint32_t sv = s.sv[w];
+    uint32_t base = w * 32u;
+#pragma unroll 4
+    for (uint32_t b = 0; b < 32; b++) {
+        uint32_t p = base + b;
+        if (p >= s.len) break;
+        uint32_t key = NBUCKET;
+        if ((sv >> b) & 1u) {
+            uint32_t wl = (uint32_t)(lo >> b) & 0x7FFFFu, wh = (uint32_t)(hi >> b) & 0x7FFFFu;
+            key = (pext12(wl) << 12) | pext12(wh);
+            atomicAdd(&hist[key], 1u);
+        }
+        keys[p] = key;
+        posv[p] = p;
+    }
+}
+
+void SeedIndex::release() {
+    if (off) (void)hipFree(off);
+    if (pos) (void)hipFree(pos);
+    off = pos = nullptr;
+    n = 0;
+}
+
+int build_index(const StrandView &s, SeedIndex &out, float *ms) {
+    out.release();
+    uint32_t len = s.len;
+    uint32_t nwords = (len + 31) / 32;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream()));
+    uint32_t *hist = nullptr;
+    HIP_TRY(hipMalloc((void **)&hist, ((size_t)NBUCKET + 2) * 4));
+    HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)NBUCKET + 2) * 4, stream()));
+    HIP_TRY(hipMalloc((void **)&out.off, ((size_t)NBUCKET + 2) * 4));
+    size_t n = len ? len : 1;
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *pos_in = nullptr;
+    HIP_TRY(hipMalloc((void **)&keys_in, n * 4));
+    HIP_TRY(hipMalloc((void **)&keys_out, n * 4));
+    HIP_TRY(hipMalloc((void **)&pos_in, n * 4));
+    HIP_TRY(hipMalloc((void **)&out.pos, n * 4));
+    if (nwords)
+        hipLaunchKernelGGL(k2_seed_keys, dim3((nwords + 255) / 256), dim3(256), 0, stream(), s, nwords, keys_in,
+                           pos_in, hist);
+    // off = exclusive scan of hist over NBUCKET+1 entries (entry NBUCKET = total)
+    size_t tmp_bytes = 0, tmp2 = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, hist, out.off, 0u, (size_t)NBUCKET + 1, rocprim::plus<uint32_t>(),
+                                    stream()));
+    if (len)
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp2, keys_in, keys_out, pos_in, out.pos, (size_t)len, 0, 25,
+                                          stream()));
+    if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, hist, out.off, 0u, (size_t)NBUCKET + 1, rocprim::plus<uint32_t>(),
+                                    stream()));
+    if (len)
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pos_in, out.pos, (size_t)len, 0, 25,
+                                          stream()));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, out.off + NBUCKET, 4, hipMemcpyDeviceToHost, stream()));
+    HIP_TRY(hipEventRecord(e1, stream()));
+    HIP_TRY(hipStreamSynchronize(stream()));
+    out.n = total;
+    if (ms) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        *ms += t;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(hipFree(tmp));
+    HIP_TRY(hipFree(hist));
+    HIP_TRY(hipFree(keys_in));
+    HIP_TRY(hipFree(keys_out));
+    HIP_TRY(hipFree(pos_in));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mimeo

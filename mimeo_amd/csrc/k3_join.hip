@@ -1,0 +1,207 @@
+// K3 — seed scan as an index join (lastz's query scan + table probes with the
+// default one-transition tolerance; reference call site src/mimeo/wrappers.py:1031,
+// `--step=1 --strand=both`).
+//
+// lastz walks the query and probes a 2^24-entry hash table 13 times per base: 104 random
+// bytes per query base.  Here BOTH sides are CSR seed indexes in the transition-closed key
+// layout of common.h, so the 13 neighbours of a word live in the same 4096-key tile: one
+// workgroup streams the two 16 KiB offset slices of a tile into LDS with coalesced 16-byte
+// loads and resolves every probe from LDS.  HBM traffic per (target, query-strand) unit is the
+// two offset arrays + the position lists once + the hit records.
+//
+// Two launches: k3_join_count (per-tile hit counts) -> k3_tile_scan -> k3_join_fill.  The fill
+// kernel places hits with a workgroup prefix sum, stages each 256-word chunk in LDS and writes
+// it out with coalesced 8-byte-per-lane stores, so the output order is deterministic:
+// (key, target position, neighbour, query position).
+#include "common.h"
+
+namespace mimeo {
+
+constexpr int JOIN_THREADS = 256;
+constexpr int JOIN_STAGE = 3072;  // hits staged in LDS per 256-word chunk (24 KiB)
+
+__device__ __forceinline__ void load_tile_offsets(const uint32_t *__restrict__ off, uint32_t tile,
+                                                  uint32_t *s) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(off + (size_t)tile * TILE_WORDS);
+    uint4 *dst = reinterpret_cast<uint4 *>(s);
+#pragma unroll
+    for (int k = 0; k < (int)(TILE_WORDS / 4 / JOIN_THREADS); k++) dst[k * JOIN_THREADS + threadIdx.x] = src[k * JOIN_THREADS + threadIdx.x];
+    if (threadIdx.x == 0) s[TILE_WORDS] = off[(size_t)tile * TILE_WORDS + TILE_WORDS];
+}
+
+__device__ __forceinline__ uint32_t neighbour_sum(const uint32_t *sQ, uint32_t w, int transitions) {
+    uint32_t sum = sQ[w + 1] - sQ[w];
+    if (transitions) {
+#pragma unroll
+        for (int j = 0; j < SEED_WEIGHT; j++) {
+            uint32_t w2 = w ^ (1u << j);
+            sum += sQ[w2 + 1] - sQ[w2];
+        }
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(JOIN_THREADS) void k3_join_count(const uint32_t *__restrict__ offT,
+                                                              const uint32_t *__restrict__ offQ, int transitions,
+                                                              unsigned long long *__restrict__ tile_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t sT[TILE_WORDS + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sQ[TILE_WORDS + 4];
+    __shared__ unsigned long long red[JOIN_THREADS / 64];
+    uint32_t tile = blockIdx.x;
+    load_tile_offsets(offT, tile, sT);
+    load_tile_offsets(offQ, tile, sQ);
+    __syncthreads();
+    unsigned long long cnt = 0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < TILE_WORDS / JOIN_THREADS; k++) {
+        uint32_t w = k * JOIN_THREADS + threadIdx.x;
+        uint32_t nT = sT[w + 1] - sT[w];
+        if (nT) cnt += (unsigned long long)nT * neighbour_sum(sQ, w, transitions);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < JOIN_THREADS / 64; i++) t += red[i];
+        tile_count[tile] = t;
+    }
+}
+
+// single workgroup: exclusive scan of the NTILE tile counts; tile_base[NTILE] = total
+__global__ __launch_bounds__(1024) void k3_tile_scan(const unsigned long long *__restrict__ cnt,
+                                                     unsigned long long *__restrict__ base) {
+    __shared__ unsigned long long part[1024];
+    constexpr int PER = NTILE / 1024;
+    unsigned long long loc[PER], s = 0;
+    for (int i = 0; i < PER; i++) { loc[i] = s; s += cnt[threadIdx.x * PER + i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        unsigned long long v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long excl = part[threadIdx.x] - s;
+    for (int i = 0; i < PER; i++) base[threadIdx.x * PER + i] = excl + loc[i];
+    if (threadIdx.x == 1023) base[NTILE] = part[1023];
+}
+
+__global__ __launch_bounds__(JOIN_THREADS) void k3_join_fill(const uint32_t *__restrict__ offT,
+                                                             const uint32_t *__restrict__ posT,
+                                                             const uint32_t *__restrict__ offQ,
+                                                             const uint32_t *__restrict__ posQ, int transitions,
+                                                             const unsigned long long *__restrict__ tile_base,
+                                                             uint2 *__restrict__ hits) {
+    __shared__ __attribute__((aligned(16))) uint32_t sT[TILE_WORDS + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sQ[TILE_WORDS + 4];
+    __shared__ uint2 stage[JOIN_STAGE];
+    __shared__ uint32_t wsum[JOIN_THREADS / 64];
+    uint32_t tile = blockIdx.x;
+    unsigned long long out = tile_base[tile];
+    if (tile_base[tile + 1] == out) return;  // empty tile
+    load_tile_offsets(offT, tile, sT);
+    load_tile_offsets(offQ, tile, sQ);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t k = 0; k < TILE_WORDS / JOIN_THREADS; k++) {
+        uint32_t w = k * JOIN_THREADS + threadIdx.x;
+        uint32_t t0 = sT[w], nT = sT[w + 1] - t0;
+        uint32_t c = nT ? nT * neighbour_sum(sQ, w, transitions) : 0;
+        // workgroup exclusive scan of c
+        uint32_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up(inc, o);
+            if (lane >= (uint32_t)o) inc += v;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < JOIN_THREADS / 64; i++) {
+            uint32_t v = wsum[i];
+            if ((uint32_t)i < wave) wbase += v;
+            total += v;
+        }
+        uint32_t o = wbase + inc - c;
+        bool staged = total <= JOIN_STAGE;
+        if (c) {
+            uint2 *dst = staged ? stage + o : hits + out + o;
+            for (uint32_t a = 0; a < nT; a++) {
+                uint32_t tp = posT[t0 + a];
+                for (int j = -1; j < (transitions ? SEED_WEIGHT : 0); j++) {
+                    uint32_t w2 = j < 0 ? w : (w ^ (1u << j));
+                    uint32_t q0 = sQ[w2], q1 = sQ[w2 + 1];
+                    for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, posQ[b]);
+                }
+            }
+        }
+        __syncthreads();
+        if (staged) {
+            for (uint32_t i = threadIdx.x; i < total; i += JOIN_THREADS) hits[out + i] = stage[i];
+            __syncthreads();
+        }
+        out += total;
+    }
+}
+
+int DeviceBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+}
+void DeviceBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+static unsigned long long *g_tile_count = nullptr, *g_tile_base = nullptr;
+static hipEvent_t g_ev[4];
+static bool g_ev_ok = false;
+
+int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
+              JoinTiming *tm) {
+    if (!g_tile_count) {
+        HIP_TRY(hipMalloc((void **)&g_tile_count, (NTILE + 2) * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&g_tile_base, (NTILE + 2) * sizeof(unsigned long long)));
+    }
+    if (!g_ev_ok) {
+        for (auto &e : g_ev) HIP_TRY(hipEventCreate(&e));
+        g_ev_ok = true;
+    }
+    hipStream_t st = stream();
+    HIP_TRY(hipEventRecord(g_ev[0], st));
+    hipLaunchKernelGGL(k3_join_count, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, Q.off, transitions, g_tile_count);
+    hipLaunchKernelGGL(k3_tile_scan, dim3(1), dim3(1024), 0, st, g_tile_count, g_tile_base);
+    HIP_TRY(hipEventRecord(g_ev[1], st));
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, g_tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *nhits = total;
+    int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_ev[2], st));
+    if (total)
+        hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, T.pos, Q.off, Q.pos, transitions,
+                           g_tile_base, (uint2 *)hits.p);
+    HIP_TRY(hipEventRecord(g_ev[3], st));
+    HIP_TRY(hipGetLastError());
+    if (tm) {
+        HIP_TRY(hipEventSynchronize(g_ev[3]));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, g_ev[0], g_ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, g_ev[2], g_ev[3]));
+        tm->ms_count += a;
+        tm->ms_fill += b;
+    }
+    return 0;
+}
+
+}  // namespace mimeo

@@ -1,0 +1,114 @@
+"""Host-side handle on the HIP engine: what the reference's `*_LZ_cmds` + `run_cmd`
+(src/mimeo/wrappers.py:899-1271, src/mimeo/utils.py:213-254) become once the shell pipeline
+is replaced by calls through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+_initialised_device = None
+
+
+def init(device=0):
+    """Bind this process to one GPU (one process per GPU)."""
+    global _initialised_device
+    lib = _ffi.load()
+    _ffi.check(lib.mimeo_init(int(device)))
+    _initialised_device = int(device)
+
+
+def default_params(**kw):
+    p = _ffi.Params()
+    _ffi.check(_ffi.load().mimeo_params_default(C.byref(p)))
+    for k, v in kw.items():
+        setattr(p, k, int(v))
+    return p
+
+
+def stats():
+    s = _ffi.Stats()
+    _ffi.check(_ffi.load().mimeo_get_stats(C.byref(s)))
+    return s.asdict()
+
+
+class Genome:
+    """Device-resident scaffolds (both strands, bit-plane packed)."""
+
+    def __init__(self, names, seqs):
+        """names: list[str]; seqs: list of bytes / uint8 arrays of ASCII bases."""
+        lib = _ffi.load()
+        self.names = list(names)
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, dtype=np.uint8)
+                for s in seqs]
+        self.lengths = [int(a.size) for a in arrs]
+        offsets = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(self.lengths, dtype=np.uint64)
+        bases = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8)
+        if bases.size == 0:
+            bases = np.zeros(1, dtype=np.uint8)
+        h = C.c_void_p()
+        _ffi.check(lib.mimeo_genome_create(len(arrs), bases.ctypes.data, offsets.ctypes.data, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            _ffi.load().mimeo_genome_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.names)
+
+
+def seed_hits(T, tid, Q, qid, qstrand=0, params=None):
+    p = params or default_params()
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_seed_hits(T._h, tid, Q._h, qid, int(qstrand), C.byref(p), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.SEED_HIT)
+
+
+def ungapped_hsps(T, tid, Q, qid, qstrand=0, params=None):
+    p = params or default_params()
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_ungapped_hsps(T._h, tid, Q._h, qid, int(qstrand), C.byref(p), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.HSP)
+
+
+def align_pair(T, tid, Q, qid, params=None):
+    p = params or default_params()
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_align_pair(T._h, tid, Q._h, qid, C.byref(p), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.ALIGNMENT)
+
+
+def align_pairs(A, B, pairs, params=None):
+    """pairs: iterable of (target index in A, query index in B or A)."""
+    p = params or default_params()
+    pr = np.asarray(list(pairs), dtype=np.uint32).reshape(-1, 2)
+    pt = np.ascontiguousarray(pr[:, 0])
+    pq = np.ascontiguousarray(pr[:, 1])
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_align_pairs(A._h, B._h if B is not None else None, pt.ctypes.data, pq.ctypes.data,
+                                             len(pt), C.byref(p), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.ALIGNMENT)
+
+
+def coverage_collapse(intervals, chrom_len, min_cov, min_len):
+    """intervals: structured array (_ffi.INTERVAL) or (n,3) ints of (chrom id, start, end)."""
+    iv = np.asarray(intervals)
+    if iv.dtype != _ffi.INTERVAL:
+        a = np.asarray(iv, dtype=np.uint32).reshape(-1, 3)
+        iv = np.zeros(a.shape[0], dtype=_ffi.INTERVAL)
+        iv['chrom'], iv['start'], iv['end'] = a[:, 0], a[:, 1], a[:, 2]
+    iv = np.ascontiguousarray(iv)
+    cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_coverage_collapse(iv.ctypes.data if iv.size else None, iv.size, cl.ctypes.data,
+                                                   cl.size, int(min_cov), int(min_len), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.INTERVAL)
