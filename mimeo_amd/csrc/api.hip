@@ -1,5 +1,6 @@
 // api.hip — the C-ABI of libmimeo_hip.so (include/mimeo_hip.h).  Host-side runtime only:
 // device selection, streams, error strings, genome handles, stage orchestration.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -179,6 +180,54 @@ int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, 
     g_stats.scan_launches = 1;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+}
+
+int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, uint32_t qstrand,
+                        const mimeo_params *p, mimeo_hsp **out, uint64_t *nout) {
+    int rc = check_pair(T, tid, Q, qid, p, out, nout);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g_stats, 0, sizeof g_stats);
+    const Scaffold &ts = T->scaf[tid], &qs = Q->scaf[qid];
+    StrandView tv = ts.fwd.view(true), qv = (qstrand ? qs.rc : qs.fwd).view(false);
+    SeedIndex it, iq;
+    float ms_index = 0, ms_ext = 0;
+    DeviceBuf hits, hsps;
+    uint64_t n = 0, nh = 0;
+    JoinTiming tm;
+    mimeo_hsp *h = nullptr;
+    do {
+        if ((rc = build_index(tv, it, &ms_index))) break;
+        if ((rc = build_index(qv, iq, &ms_index))) break;
+        if ((rc = join_hits(it.view(), iq.view(), p->transitions, hits, &n, &tm))) break;
+        if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)hits.p, n, p, hsps, &nh, &ms_ext))) break;
+        h = (mimeo_hsp *)malloc((nh ? nh : 1) * sizeof(mimeo_hsp));
+        if (!h) { set_error("host allocation failed"); rc = MIMEO_ERR_NOMEM; break; }
+        if (nh) {
+            hipError_t e = hipMemcpy(h, hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpy(hsps)", __FILE__, __LINE__); break; }
+        }
+        std::sort(h, h + nh, [](const mimeo_hsp &a, const mimeo_hsp &b) {
+            int64_t da = (int64_t)a.tstart - a.qstart, db = (int64_t)b.tstart - b.qstart;
+            if (da != db) return da < db;
+            return a.tstart < b.tstart;
+        });
+    } while (0);
+    hits.release(); hsps.release(); it.release(); iq.release();
+    if (rc) { free(h); return rc; }
+    *out = h;
+    *nout = nh;
+    g_stats.pair_strands = 1;
+    g_stats.seed_hits = n;
+    g_stats.hsps = nh;
+    g_stats.query_bases_scanned = qs.len;
+    g_stats.ms_index = ms_index;
+    g_stats.ms_scan = tm.ms_count + tm.ms_fill;
+    g_stats.ms_scan_fill = tm.ms_fill;
+    g_stats.scan_launches = 1;
+    g_stats.ms_extend = ms_ext;
+    g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MIMEO_OK;
 }
 
 }  // extern "C"

@@ -106,4 +106,8 @@ struct JoinTiming { float ms_count = 0, ms_fill = 0; };
 int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
               JoinTiming *tm);
 
+// K4: seed hits -> HSPs (k4_extend.hip); out_hsps holds mimeo_hsp records on the device
+int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
+                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms);
+
 }  // namespace mimeo

@@ -1,0 +1,474 @@
+// K4 — gap-free x-drop extension of seed hits into HSPs with lastz's per-diagonal "already
+// extended" suppression, --entropy and --hspthresh (reference call site
+// src/mimeo/wrappers.py:1031-1032 `--gfextend --entropy --hspthresh=H`).
+//
+// lastz resolves the suppression sequentially (one diagonal-extent array updated while the
+// query is scanned).  The same result is obtained here without ordering the hit flood
+// (DESIGN.md §4, K4):
+//   * k4_extend_hits — one lane per hit, stateless.  While walking left from the seed end the
+//     lane also looks, bit-parallel, for an earlier seed hit on its own diagonal whose seed
+//     end lies at a position the walk reached.  If there is none the hit is a HEAD: no earlier
+//     extension can cover it, so it is certainly extended by the sequential process; the lane
+//     finishes the extension and emits a candidate HSP if it scores >= hspthresh.  Otherwise
+//     the hit is a FOLLOWER and only (diagonal, seed end, nearest earlier seed end) is kept.
+//   * followers are sorted by (diagonal, seed end); a run whose members each name their
+//     predecessor is a segment owned by the head in front of it; k4_resolve_segments replays
+//     lastz's rule inside each segment with one wavefront (extend, skip everything whose seed
+//     end <= reach, extend the next one, ...).
+//   * walks longer than LONG_CAP bases are finished by k4_extend_long, one wavefront per hit,
+//     64 bases per step with wave-level prefix sums.
+//   * k4_entropy applies the entropy adjustment to candidates and the threshold.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace mimeo {
+
+constexpr uint32_t CARE19 = 0x7A997u;  // care positions of 1110100110010101111 (bit i = offset i)
+constexpr int EXT_THREADS = 256;
+constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per direction
+
+struct ExtCounters {
+    unsigned long long ncand, nfollow, nlong, nhsp;
+};
+
+struct Cand {
+    uint32_t tstart, qstart, len;
+    int32_t raw;
+};
+
+// ---- plane access ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t get32(const uint32_t *__restrict__ pl, int32_t s) {
+    int32_t w = s >> 5;
+    uint32_t b = (uint32_t)s & 31u;
+    uint64_t v = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
+    return (uint32_t)(v >> b);
+}
+__device__ __forceinline__ uint64_t get64(const uint32_t *__restrict__ pl, int32_t s) {
+    int32_t w = s >> 5;
+    uint32_t b = (uint32_t)s & 31u;
+    uint64_t lo = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
+    uint64_t hi = pl[w + 2];
+    return b ? (lo >> b) | (hi << (64 - b)) : lo;
+}
+
+// HOXD70 + N = -100 from the difference planes: dl/dh = xor of the lo/hi planes, cg = target
+// base is C or G, nn = either base is N.
+__device__ __forceinline__ int32_t sub_score(uint32_t dl, uint32_t dh, uint32_t cg, uint32_t nn) {
+    uint32_t tb = dl ? 0x83858E8Eu : 0xE1E1645Bu;  // {-114,-114,-123,-125} : {91,100,-31,-31}
+    uint32_t sh = 24u - (((dh << 1) | cg) << 3);
+    int32_t s = ((int32_t)(tb << sh)) >> 24;
+    return nn ? -100 : s;
+}
+
+// is there a seed hit whose 19-window starts at target position p (query p - d)?
+__device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandView &Q, int32_t p, int32_t d,
+                                            int transitions) {
+    int32_t pq = p - d;
+    if (!((get32(T.sv, p) & get32(Q.sv, pq)) & 1u)) return false;
+    uint32_t dl = (get32(T.lo, p) ^ get32(Q.lo, pq)) & CARE19;
+    uint32_t dh = (get32(T.hi, p) ^ get32(Q.hi, pq)) & CARE19;
+    if (!transitions) return (dl | dh) == 0;
+    return dl == 0 && __popc(dh) <= 1;
+}
+
+// ---- K4a: one lane per hit --------------------------------------------------------------
+__global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
+                                                              const uint2 *__restrict__ hits, uint64_t nhits,
+                                                              int xdrop, int hspthresh, int transitions,
+                                                              ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
+                                                              uint64_t cand_cap, uint64_t *__restrict__ fkey,
+                                                              uint32_t *__restrict__ fprev,
+                                                              uint2 *__restrict__ longq) {
+    uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
+    if (gid >= nhits) return;
+    uint2 h = hits[gid];
+    const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
+    const int32_t d = (int32_t)h.x - (int32_t)h.y;
+    // ---- left walk, with detection of an earlier seed hit at every reached boundary
+    int32_t run = 0, best = 0;
+    uint32_t bl = 0, k = 0;
+    const uint32_t maxl = (uint32_t)min(et, eq);
+    bool done = false, found = false, is_long = false;
+    uint32_t prev_end = 0;
+    for (int win = 0; !done; win++) {
+        if (win == LONG_WINDOWS) { is_long = true; break; }
+        int32_t P = et - 32 * (win + 1) - SEED_LEN, Pq = P - d;
+        uint64_t tlo = get64(T.lo, P), thi = get64(T.hi, P);
+        uint64_t dl64 = tlo ^ get64(Q.lo, Pq), dh64 = thi ^ get64(Q.hi, Pq);
+        uint64_t nm = dl64 | dh64, ones = 0, twos = 0, tv = 0;
+#pragma unroll
+        for (int c = 0; c < SEED_LEN; c++) {
+            if (!((CARE19 >> c) & 1u)) continue;
+            uint64_t v = nm >> c;
+            twos |= ones & v;
+            ones |= v;
+            tv |= dl64 >> c;
+        }
+        uint64_t bad = transitions ? (twos | tv) : ones;
+        uint32_t H = ~(uint32_t)bad & get32(T.sv, P) & get32(Q.sv, Pq);
+        uint32_t wdl = (uint32_t)(dl64 >> SEED_LEN), wdh = (uint32_t)(dh64 >> SEED_LEN);
+        uint32_t wcg = (uint32_t)((tlo ^ thi) >> SEED_LEN);
+        uint32_t wnn = get32(T.nm, P + SEED_LEN) | get32(Q.nm, Pq + SEED_LEN);
+        for (int b = 31; b >= 0; b--) {
+            if (k >= maxl) { done = true; break; }
+            k++;
+            run += sub_score((wdl >> b) & 1u, (wdh >> b) & 1u, (wcg >> b) & 1u, (wnn >> b) & 1u);
+            if (run > best) { best = run; bl = k; }
+            if (run < best - xdrop) { done = true; break; }
+            if ((H >> b) & 1u) { found = true; prev_end = (uint32_t)(P + SEED_LEN + b); done = true; break; }
+        }
+    }
+    if (is_long) {
+        unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
+        longq[i] = h;
+        return;
+    }
+    if (found) {
+        unsigned long long i = atomicAdd(&ctr->nfollow, 1ull);
+        fkey[i] = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
+        fprev[i] = prev_end;
+        return;
+    }
+    // ---- right walk
+    int32_t runr = 0, bestr = 0;
+    uint32_t br = 0, kr = 0;
+    const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
+    done = false;
+    for (int win = 0; !done; win++) {
+        if (win == LONG_WINDOWS) { is_long = true; break; }
+        int32_t P = et + 32 * win, Pq = P - d;
+        uint32_t tlo = get32(T.lo, P), thi = get32(T.hi, P);
+        uint32_t wdl = tlo ^ get32(Q.lo, Pq), wdh = thi ^ get32(Q.hi, Pq), wcg = tlo ^ thi;
+        uint32_t wnn = get32(T.nm, P) | get32(Q.nm, Pq);
+        for (int b = 0; b < 32; b++) {
+            if (kr >= maxr) { done = true; break; }
+            kr++;
+            runr += sub_score((wdl >> b) & 1u, (wdh >> b) & 1u, (wcg >> b) & 1u, (wnn >> b) & 1u);
+            if (runr > bestr) { bestr = runr; br = kr; }
+            if (runr < bestr - xdrop) { done = true; break; }
+        }
+    }
+    if (is_long) {
+        unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
+        longq[i] = h;
+        return;
+    }
+    int32_t score = best + bestr;
+    if (score >= hspthresh) {
+        unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
+        if (i < cand_cap) cand[i] = Cand{(uint32_t)et - bl, (uint32_t)eq - bl, bl + br, score};
+    }
+}
+
+// ---- wave-cooperative walk: 64 bases per step ---------------------------------------------
+struct WalkResult {
+    int64_t best;     // best prefix score
+    uint32_t bsteps;  // number of steps in the best prefix
+    bool found;       // (left + detect) an earlier seed hit ends at a reached boundary
+    uint32_t prev_end;
+};
+
+__device__ __forceinline__ int64_t wave_incl_sum(int64_t v, uint32_t lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        int64_t u = __shfl_up(v, o);
+        if (lane >= (uint32_t)o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int64_t wave_incl_max(int64_t v, uint32_t lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        int64_t u = __shfl_up(v, o);
+        if (lane >= (uint32_t)o) v = max(v, u);
+    }
+    return v;
+}
+__device__ __forceinline__ int64_t wave_max(int64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// dir = -1: steps visit et-1, et-2, ...;  dir = +1: et, et+1, ...   All lanes return the same value.
+__device__ WalkResult wave_walk(const StrandView &T, const StrandView &Q, int32_t et, int32_t d, int dir,
+                                uint32_t maxsteps, int xdrop, bool detect, int transitions) {
+    const uint32_t lane = threadIdx.x & 63u;
+    WalkResult r{0, 0, false, 0};
+    int64_t run = 0;
+    for (uint32_t k0 = 0; k0 < maxsteps; k0 += 64) {
+        uint32_t i = k0 + lane;
+        bool active = i < maxsteps;
+        int32_t pt = dir < 0 ? et - 1 - (int32_t)i : et + (int32_t)i;
+        int32_t pq = pt - d;
+        int64_t s = 0;
+        if (active) {
+            uint32_t tlo = get32(T.lo, pt) & 1u, thi = get32(T.hi, pt) & 1u;
+            uint32_t dl = tlo ^ (get32(Q.lo, pq) & 1u), dh = thi ^ (get32(Q.hi, pq) & 1u);
+            uint32_t nn = (get32(T.nm, pt) | get32(Q.nm, pq)) & 1u;
+            s = sub_score(dl, dh, tlo ^ thi, nn);
+        }
+        int64_t P = run + wave_incl_sum(s, lane);
+        int64_t M = max(r.best, wave_incl_max(P, lane));
+        bool brk = active && (P < M - xdrop);
+        uint64_t bmask = __ballot(brk);
+        uint32_t f = bmask ? (uint32_t)__builtin_ctzll(bmask) : 64u;  // first breaking lane
+        uint32_t nact = min(64u, maxsteps - k0);
+        if (detect) {
+            bool hit = active && lane < f && seed_hit_at(T, Q, pt - SEED_LEN, d, transitions);
+            uint64_t hmask = __ballot(hit);
+            if (hmask) {
+                uint32_t g = (uint32_t)__builtin_ctzll(hmask);
+                r.found = true;
+                r.prev_end = (uint32_t)(et - 1 - (int32_t)(k0 + g));
+                return r;
+            }
+        }
+        uint32_t lim = min(f, nact - 1);  // last executed lane (the breaking step itself is executed)
+        int64_t cm = wave_max(lane <= lim ? P : INT64_MIN);
+        if (cm > r.best) {
+            uint64_t em = __ballot(lane <= lim && P == cm);
+            r.best = cm;
+            r.bsteps = k0 + (uint32_t)__builtin_ctzll(em) + 1;
+        }
+        run = __shfl(P, (int)lim);
+        if (f < 64) break;
+    }
+    return r;
+}
+
+// full extension of one hit by one wavefront; emits candidate or follower record (lane 0)
+__device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2 h, int xdrop, int hspthresh,
+                                 int transitions, bool detect, ExtCounters *ctr, Cand *cand, uint64_t cand_cap,
+                                 uint64_t *fkey, uint32_t *fprev, uint32_t *rext_out) {
+    const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN, d = (int32_t)h.x - (int32_t)h.y;
+    WalkResult L = wave_walk(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop, detect, transitions);
+    if (L.found) {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long i = atomicAdd(&ctr->nfollow, 1ull);
+            fkey[i] = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
+            fprev[i] = L.prev_end;
+        }
+        return;
+    }
+    WalkResult R = wave_walk(T, Q, et, d, +1, min(T.len - (uint32_t)et, Q.len - (uint32_t)eq), xdrop, false,
+                             transitions);
+    if (rext_out) *rext_out = R.bsteps;
+    int64_t score = L.best + R.best;
+    if (score >= hspthresh && (threadIdx.x & 63) == 0) {
+        unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
+        if (i < cand_cap)
+            cand[i] = Cand{(uint32_t)et - L.bsteps, (uint32_t)eq - L.bsteps, L.bsteps + R.bsteps, (int32_t)score};
+    }
+}
+
+// ---- K4b: long hits, one wavefront each ------------------------------------------------
+__global__ __launch_bounds__(EXT_THREADS) void k4_extend_long(StrandView T, StrandView Q,
+                                                              const uint2 *__restrict__ longq, int xdrop,
+                                                              int hspthresh, int transitions,
+                                                              ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
+                                                              uint64_t cand_cap, uint64_t *__restrict__ fkey,
+                                                              uint32_t *__restrict__ fprev) {
+    uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
+    if (wid >= ctr->nlong) return;
+    wave_extend_emit(T, Q, longq[wid], xdrop, hspthresh, transitions, true, ctr, cand, cand_cap, fkey, fprev, nullptr);
+}
+
+// ---- K4c: follower segments ----------------------------------------------------------------
+// flag[i] = 1 iff sorted follower i starts a segment (its predecessor is a head, not follower i-1)
+__global__ void k4_segment_flags(const uint64_t *__restrict__ key, const uint32_t *__restrict__ prev, uint64_t n,
+                                 uint8_t *__restrict__ flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool start = true;
+    if (i > 0) {
+        uint64_t a = key[i - 1], b = key[i];
+        start = (a >> 32) != (b >> 32) || (uint32_t)a != prev[i];
+    }
+    flag[i] = start ? 1 : 0;
+}
+
+// one wavefront per segment: replay "skip while seed end <= reach, else extend" (lastz diagEnd rule)
+__global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T, StrandView Q,
+                                                                   const uint64_t *__restrict__ key,
+                                                                   const uint32_t *__restrict__ prev, uint64_t nfollow,
+                                                                   const uint64_t *__restrict__ seg_start,
+                                                                   uint64_t nseg, int xdrop, int hspthresh,
+                                                                   int transitions, ExtCounters *__restrict__ ctr,
+                                                                   Cand *__restrict__ cand, uint64_t cand_cap) {
+    uint64_t sid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
+    if (sid >= nseg) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
+    uint64_t k0 = key[beg];
+    const int32_t d = (int32_t)(uint32_t)(k0 >> 32) - (int32_t)Q.len;
+    // head: seed end = prev[beg]; only its right extent matters (it was emitted by K4a/K4b)
+    int32_t het = (int32_t)prev[beg];
+    WalkResult R = wave_walk(T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop, false,
+                             transitions);
+    uint32_t reach = (uint32_t)het + R.bsteps;
+    uint64_t i = beg;
+    while (i < end) {
+        // first member at or after i whose seed end lies beyond reach
+        uint64_t nxt = end;
+        for (uint64_t j = i; j < end; j += 64) {
+            uint64_t jj = j + lane;
+            bool ok = jj < end && (uint32_t)key[jj] > reach;
+            uint64_t m = __ballot(ok);
+            if (m) { nxt = j + (uint64_t)__builtin_ctzll(m); break; }
+        }
+        if (nxt >= end) break;
+        uint32_t et = (uint32_t)key[nxt];
+        uint2 h = make_uint2(et - SEED_LEN, (uint32_t)((int32_t)et - d) - SEED_LEN);
+        uint32_t rext = 0;
+        wave_extend_emit(T, Q, h, xdrop, hspthresh, transitions, false, ctr, cand, cand_cap, nullptr, nullptr, &rext);
+        reach = et + rext;
+        i = nxt + 1;
+    }
+}
+
+// ---- K4d: entropy adjustment + threshold, one wavefront per candidate --------------------
+__global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandView Q, const Cand *__restrict__ cand,
+                                                          uint64_t ncand, int hspthresh, int entropy,
+                                                          ExtCounters *__restrict__ ctr, mimeo_hsp *__restrict__ out) {
+    uint64_t cid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
+    if (cid >= ncand) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    Cand c = cand[cid];
+    int64_t adj = c.raw;
+    if (entropy) {
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
+        for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 64u * 32u) {
+            int32_t pt = (int32_t)(c.tstart + w0), pq = pt - d;
+            uint32_t tlo = get32(T.lo, pt), thi = get32(T.hi, pt);
+            uint32_t m = ~((tlo ^ get32(Q.lo, pq)) | (thi ^ get32(Q.hi, pq))) & ~(get32(T.nm, pt) | get32(Q.nm, pq));
+            uint32_t rem = c.len - w0;
+            if (rem < 32) m &= (1u << rem) - 1u;
+            cnt[0] += __popc(m & ~tlo & ~thi);
+            cnt[1] += __popc(m & tlo & ~thi);
+            cnt[2] += __popc(m & ~tlo & thi);
+            cnt[3] += __popc(m & tlo & thi);
+        }
+        for (int b = 0; b < 4; b++)
+            for (int o = 32; o > 0; o >>= 1) cnt[b] += __shfl_xor(cnt[b], o);
+        uint64_t n = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        double hh = 0.0;
+        if (n) {
+            for (int b = 0; b < 4; b++)
+                if (cnt[b]) { double p = (double)cnt[b] / (double)n; hh -= p * log(p); }
+            hh /= log(4.0);
+        }
+        int64_t q16 = (int64_t)floor(hh * 65536.0 + 0.5);
+        q16 = q16 > 65536 ? 65536 : (q16 < 0 ? 0 : q16);
+        adj = ((int64_t)c.raw * q16) >> 16;
+    }
+    if (adj >= hspthresh && lane == 0) {
+        unsigned long long i = atomicAdd(&ctr->nhsp, 1ull);
+        mimeo_hsp h;
+        h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = c.raw;
+        out[i] = h;
+    }
+}
+
+// ---- host orchestration ---------------------------------------------------------------------
+struct ExtWork {
+    ExtCounters *ctr = nullptr;  // device
+    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, flags, segs, tmp, nsel;
+};
+static ExtWork W;
+
+int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
+                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms) {
+    hipStream_t st = stream();
+    *nhsp = 0;
+    if (T.len >= 0x7FFFFF00u || Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
+    if (!W.ctr) HIP_TRY(hipMalloc((void **)&W.ctr, sizeof(ExtCounters)));
+    HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+    if (!nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    uint64_t cand_cap = nhits / 4 + 65536;
+    int rc;
+    ExtCounters c;
+    for (int attempt = 0;; attempt++) {
+        if ((rc = W.cand.reserve(cand_cap * sizeof(Cand)))) return rc;
+        if ((rc = W.fkey.reserve(nhits * 8))) return rc;
+        if ((rc = W.fprev.reserve(nhits * 4))) return rc;
+        if ((rc = W.longq.reserve(nhits * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+        uint64_t nb = (nhits + EXT_THREADS - 1) / EXT_THREADS;
+        hipLaunchKernelGGL(k4_extend_hits, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
+                           p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                           (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+        HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c.nlong) {
+            uint64_t nbl = (c.nlong * 64 + EXT_THREADS - 1) / EXT_THREADS;
+            hipLaunchKernelGGL(k4_extend_long, dim3((uint32_t)nbl), dim3(EXT_THREADS), 0, st, T, Q,
+                               (const uint2 *)W.longq.p, p->xdrop, p->hspthresh, p->transitions, W.ctr,
+                               (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p);
+            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (c.nfollow) {
+            uint64_t nf = c.nfollow;
+            if ((rc = W.fkey2.reserve(nf * 8))) return rc;
+            if ((rc = W.fprev2.reserve(nf * 4))) return rc;
+            if ((rc = W.flags.reserve(nf))) return rc;
+            if ((rc = W.segs.reserve(nf * 8))) return rc;
+            if ((rc = W.nsel.reserve(16))) return rc;
+            size_t t1 = 0, t2 = 0;
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)W.fkey.p, (uint64_t *)W.fkey2.p,
+                                              (uint32_t *)W.fprev.p, (uint32_t *)W.fprev2.p, (size_t)nf, 0, 64, st));
+            rocprim::counting_iterator<uint64_t> iota(0);
+            HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)W.flags.p, (uint64_t *)W.segs.p,
+                                    (uint64_t *)W.nsel.p, (size_t)nf, st));
+            if ((rc = W.tmp.reserve(std::max(t1, t2) + 16))) return rc;
+            HIP_TRY(rocprim::radix_sort_pairs(W.tmp.p, t1, (uint64_t *)W.fkey.p, (uint64_t *)W.fkey2.p,
+                                              (uint32_t *)W.fprev.p, (uint32_t *)W.fprev2.p, (size_t)nf, 0, 64, st));
+            hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st,
+                               (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf, (uint8_t *)W.flags.p);
+            HIP_TRY(rocprim::select(W.tmp.p, t2, iota, (uint8_t *)W.flags.p, (uint64_t *)W.segs.p,
+                                    (uint64_t *)W.nsel.p, (size_t)nf, st));
+            uint64_t nseg = 0;
+            HIP_TRY(hipMemcpyAsync(&nseg, W.nsel.p, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (nseg) {
+                uint64_t nbs = (nseg * 64 + EXT_THREADS - 1) / EXT_THREADS;
+                hipLaunchKernelGGL(k4_resolve_segments, dim3((uint32_t)nbs), dim3(EXT_THREADS), 0, st, T, Q,
+                                   (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
+                                   (const uint64_t *)W.segs.p, nseg, p->xdrop, p->hspthresh, p->transitions, W.ctr,
+                                   (Cand *)W.cand.p, cand_cap);
+            }
+            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (c.ncand <= cand_cap) break;
+        if (attempt) { set_error("candidate buffer overflow"); return MIMEO_ERR_LIMIT; }
+        cand_cap = c.ncand + 1024;  // rerun with room for every candidate
+    }
+    if ((rc = out_hsps.reserve((c.ncand ? c.ncand : 1) * sizeof(mimeo_hsp)))) return rc;
+    if (c.ncand) {
+        uint64_t nbc = (c.ncand * 64 + EXT_THREADS - 1) / EXT_THREADS;
+        hipLaunchKernelGGL(k4_entropy, dim3((uint32_t)nbc), dim3(EXT_THREADS), 0, st, T, Q, (const Cand *)W.cand.p,
+                           (uint64_t)c.ncand, p->hspthresh, p->entropy, W.ctr, (mimeo_hsp *)out_hsps.p);
+        HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    *nhsp = c.nhsp;
+    if (ms) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        *ms += t;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
+}  // namespace mimeo

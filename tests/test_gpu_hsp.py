@@ -1,0 +1,95 @@
+"""K4 parity: HSPs from the stateless-extension + segment-resolution kernels must equal the
+oracle's sequential lastz-shaped scan, bit for bit."""
+import numpy as np
+import pytest
+
+from mimeo_amd.synth import synth_genome
+
+pytestmark = pytest.mark.gpu
+
+COLS = ['tstart', 'qstart', 'length', 'score', 'raw_score']
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mimeo_amd import engine
+    engine.init(0)
+    return engine
+
+
+def _cmp(got, exp, tag):
+    a = np.sort(got[COLS], order=COLS)
+    b = np.sort(exp[COLS], order=COLS)
+    assert a.size == b.size, (tag, a.size, b.size)
+    bad = np.flatnonzero(a != b)
+    assert bad.size == 0, (tag, a[bad[:5]], b[bad[:5]])
+
+
+@pytest.mark.parametrize('seed,div,indel', [(21, 0.15, 0.005), (22, 0.02, 0.0), (23, 0.25, 0.02)])
+def test_hsps_match_oracle_cross(eng, seed, div, indel):
+    from oracle import oracle as O
+    names, seqs = synth_genome(seed, 400_000, 2, repeat_frac=0.15, families=5, cons_len=(200, 3000),
+                               max_div=div, indel_rate=indel)
+    g = eng.Genome(names, seqs)
+    for strand in (0, 1):
+        got = eng.ungapped_hsps(g, 0, g, 1, strand, eng.default_params(chain=0))
+        exp = O.ungapped_hsps(seqs[0].tobytes(), seqs[1].tobytes(), strand, O.default_params(chain=0))
+        assert exp.size > 10
+        _cmp(got, exp, (seed, strand))
+    g.close()
+
+
+def test_hsps_self_pair_trivial_diagonal(eng):
+    """(A,A) without --self: the full-length diagonal is one HSP found by the long-walk kernel,
+    and every other hit on it is a follower that must be skipped."""
+    from oracle import oracle as O
+    names, seqs = synth_genome(31, 300_000, 1, repeat_frac=0.1, families=3, cons_len=(300, 2000))
+    g = eng.Genome(names, seqs)
+    for strand in (0, 1):
+        got = eng.ungapped_hsps(g, 0, g, 0, strand, eng.default_params(chain=0))
+        exp = O.ungapped_hsps(seqs[0].tobytes(), seqs[0].tobytes(), strand, O.default_params(chain=0))
+        _cmp(got, exp, ('self', strand))
+        if strand == 0:
+            assert got['length'].max() == 300_000
+    g.close()
+
+
+def test_hsps_with_n_runs_lowercase_and_no_entropy(eng):
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    names, seqs = synth_genome(41, 300_000, 2, repeat_frac=0.2, families=3, cons_len=(500, 3000), max_div=0.05)
+    T, Q = seqs[0].copy(), seqs[1].copy()
+    for s in (T, Q):
+        for _ in range(40):
+            p = int(rng.integers(0, s.size - 400))
+            s[p:p + int(rng.integers(1, 60))] = ord('N')
+        for _ in range(40):
+            p = int(rng.integers(0, s.size - 400))
+            s[p:p + int(rng.integers(1, 300))] |= 0x20
+    g = eng.Genome(['t', 'q'], [T, Q])
+    for ent in (1, 0):
+        for strand in (0, 1):
+            got = eng.ungapped_hsps(g, 0, g, 1, strand, eng.default_params(chain=0, entropy=ent))
+            exp = O.ungapped_hsps(T.tobytes(), Q.tobytes(), strand, O.default_params(chain=0, entropy=ent))
+            _cmp(got, exp, ('mask', ent, strand))
+    g.close()
+
+
+def test_hsps_low_complexity(eng):
+    """Microsatellites: many hits per diagonal, staggered diagonals, entropy adjustment bites."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(9)
+    names, seqs = synth_genome(51, 120_000, 2, repeat_frac=0.0)
+    T, Q = seqs[0].copy(), seqs[1].copy()
+    for unit in (b'A', b'AC', b'AAG', b'ACGT', b'AAAAG', b'ACACGT'):
+        for s in (T, Q):
+            p = int(rng.integers(0, s.size - 2000))
+            ln = int(rng.integers(200, 900))
+            rep = np.frombuffer((unit * (ln // len(unit) + 1))[:ln], dtype=np.uint8)
+            s[p:p + ln] = rep
+    g = eng.Genome(['t', 'q'], [T, Q])
+    for strand in (0, 1):
+        got = eng.ungapped_hsps(g, 0, g, 1, strand, eng.default_params(chain=0))
+        exp = O.ungapped_hsps(T.tobytes(), Q.tobytes(), strand, O.default_params(chain=0))
+        _cmp(got, exp, ('ssr', strand))
+    g.close()
