@@ -230,4 +230,38 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
     return MIMEO_OK;
 }
 
+int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!A || !p || !out || !nout || (npairs && (!pair_t || !pair_q))) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    return align_pairs_impl(A, B, pair_t, pair_q, npairs, p, out, nout);
+}
+
+int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, const mimeo_params *p,
+                     mimeo_alignment **out, uint64_t *nout) {
+    int rc = check_pair(T, tid, Q, qid, p, out, nout);
+    if (rc) return rc;
+    return align_pairs_impl(T, Q, &tid, &qid, 1, p, out, nout);
+}
+
+int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t *chrom_len, uint32_t nchrom,
+                            uint32_t min_cov, uint32_t min_len, mimeo_interval **out, uint64_t *nout) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!out || !nout || (n && !iv) || (nchrom && !chrom_len)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    std::vector<mimeo_interval> res;
+    float ms = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if ((rc = coverage_collapse_device(iv, n, chrom_len, nchrom, min_cov, min_len, res, &ms))) return rc;
+    mimeo_interval *r = (mimeo_interval *)malloc((res.size() ? res.size() : 1) * sizeof(mimeo_interval));
+    if (!r) { set_error("host allocation failed"); return MIMEO_ERR_NOMEM; }
+    if (!res.empty()) memcpy(r, res.data(), res.size() * sizeof(mimeo_interval));
+    *out = r;
+    *nout = res.size();
+    g_stats.ms_collapse = ms;
+    (void)t0;
+    return MIMEO_OK;
+}
+
 }  // extern "C"

@@ -110,4 +110,25 @@ int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf
 int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms);
 
+// K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
+struct Group {
+    StrandView T, Q;
+    uint32_t tid, qid, minus, nchain;
+    uint64_t hsp_begin, hsp_end;
+    uint32_t naln, overflow;
+};
+// chain + gapped extension of every group; alignments of group g land at d_aln[hsp_begin ..
+// hsp_begin + naln) (k5_chain_gapped.hip)
+int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps,
+                        const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,
+                        float *ms_gapped);
+
+// K7: coverage collapse (k7_collapse.hip); host in, host out (sorted by chrom, start)
+int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint32_t *h_chrom_len, uint32_t nchrom,
+                             uint32_t min_cov, uint32_t min_len, std::vector<mimeo_interval> &out, float *ms);
+
+// whole-job loop (pipeline.hip)
+int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+                     uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
+
 }  // namespace mimeo

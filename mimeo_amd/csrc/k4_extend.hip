@@ -22,7 +22,7 @@
 
 #include <rocprim/rocprim.hpp>
 
-#include "common.h"
+#include "device_util.h"
 
 namespace mimeo {
 
@@ -38,30 +38,6 @@ struct Cand {
     uint32_t tstart, qstart, len;
     int32_t raw;
 };
-
-// ---- plane access ---------------------------------------------------------------------
-__device__ __forceinline__ uint32_t get32(const uint32_t *__restrict__ pl, int32_t s) {
-    int32_t w = s >> 5;
-    uint32_t b = (uint32_t)s & 31u;
-    uint64_t v = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
-    return (uint32_t)(v >> b);
-}
-__device__ __forceinline__ uint64_t get64(const uint32_t *__restrict__ pl, int32_t s) {
-    int32_t w = s >> 5;
-    uint32_t b = (uint32_t)s & 31u;
-    uint64_t lo = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
-    uint64_t hi = pl[w + 2];
-    return b ? (lo >> b) | (hi << (64 - b)) : lo;
-}
-
-// HOXD70 + N = -100 from the difference planes: dl/dh = xor of the lo/hi planes, cg = target
-// base is C or G, nn = either base is N.
-__device__ __forceinline__ int32_t sub_score(uint32_t dl, uint32_t dh, uint32_t cg, uint32_t nn) {
-    uint32_t tb = dl ? 0x83858E8Eu : 0xE1E1645Bu;  // {-114,-114,-123,-125} : {91,100,-31,-31}
-    uint32_t sh = 24u - (((dh << 1) | cg) << 3);
-    int32_t s = ((int32_t)(tb << sh)) >> 24;
-    return nn ? -100 : s;
-}
 
 // is there a seed hit whose 19-window starts at target position p (query p - d)?
 __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandView &Q, int32_t p, int32_t d,

@@ -1,0 +1,170 @@
+// pipeline.hip — host orchestration of the per-pair loop of run_jobs.sh
+// (src/mimeo/wrappers.py:1015-1059 in the reference): mimeo_align_pairs / mimeo_align_pair.
+//
+// Pairs are grouped by target scaffold.  A scaffold strand's seed index is built once and
+// kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  For
+// each target: every (query, strand) unit runs K3 (index join) and K4 (gap-free extension); the
+// HSPs of all units of the target are then chained and gap-extended in one launch pair (K5/K6,
+// one workgroup per unit).
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <tuple>
+
+#include "common.h"
+
+namespace mimeo {
+
+extern mimeo_stats g_stats;
+
+struct IndexCache {
+    // key: (scaffold address, strand, target-role sv plane in use)
+    std::map<std::tuple<const Scaffold *, int, int>, SeedIndex> m;
+    float ms = 0;
+    int get(const Scaffold &s, int minus, bool as_target, IndexView *out, StrandView *sv) {
+        bool tsv = as_target && !minus && s.fwd.sv_target != nullptr;
+        const Strand &st = minus ? s.rc : s.fwd;
+        *sv = st.view(tsv);
+        auto key = std::make_tuple(&s, minus, tsv ? 1 : 0);
+        auto it = m.find(key);
+        if (it == m.end()) {
+            SeedIndex idx;
+            int rc = build_index(*sv, idx, &ms);
+            if (rc) return rc;
+            it = m.emplace(key, idx).first;
+        }
+        *out = it->second.view();
+        return 0;
+    }
+    void clear() {
+        for (auto &kv : m) kv.second.release();
+        m.clear();
+    }
+};
+
+static uint64_t scan_bytes_algorithmic(uint64_t Lq, uint64_t H) {
+    // B_scan = ceil(Lq/4) + 8*W*(Lq-18) + 4*H + 8*H, W = 13
+    return (Lq + 3) / 4 + (Lq > 18 ? 8ull * 13ull * (Lq - 18) : 0) + 12ull * H;
+}
+static uint64_t scan_bytes_kernel(uint64_t nT, uint64_t nQ, uint64_t H) {
+    // compulsory traffic of the index join: both offset arrays, both position lists once, hits out
+    return 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 4ull * (nT + nQ) + 8ull * H;
+}
+
+static DeviceBuf g_hits, g_unit_hsps, g_all_hsps, g_scratch, g_aln, g_groups;
+
+int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+                     uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
+    auto t0 = std::chrono::steady_clock::now();
+    memset(&g_stats, 0, sizeof g_stats);
+    const mimeo_genome *QG = B ? B : A;
+    for (uint64_t k = 0; k < npairs; k++)
+        if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
+    // stable grouping of pair indices by target
+    std::vector<uint64_t> ord(npairs);
+    for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) { return pair_t[a] < pair_t[b]; });
+    std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
+    IndexCache cache;
+    JoinTiming tm;
+    float ms_ext = 0, ms_chain = 0, ms_gapped = 0;
+    hipStream_t st = stream();
+    int rc = 0;
+    uint64_t pos = 0;
+    while (pos < npairs && !rc) {
+        uint32_t tid = pair_t[ord[pos]];
+        uint64_t end = pos;
+        while (end < npairs && pair_t[ord[end]] == tid) end++;
+        const Scaffold &ts = A->scaf[tid];
+        IndexView ti;
+        StrandView tv;
+        if ((rc = cache.get(ts, 0, true, &ti, &tv))) break;
+        std::vector<Group> groups;
+        std::vector<uint64_t> group_pair;
+        uint64_t nh_total = 0;
+        for (uint64_t k = pos; k < end && !rc; k++) {
+            uint32_t qid = pair_q[ord[k]];
+            const Scaffold &qs = QG->scaf[qid];
+            for (int minus = 0; minus < 2 && !rc; minus++) {
+                if (!(p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))) continue;
+                IndexView qi;
+                StrandView qv;
+                if ((rc = cache.get(qs, minus, false, &qi, &qv))) break;
+                uint64_t nhits = 0, nh = 0;
+                if ((rc = join_hits(ti, qi, p->transitions, g_hits, &nhits, &tm))) break;
+                if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)g_hits.p, nhits, p, g_unit_hsps, &nh, &ms_ext))) break;
+                // append this unit's HSPs to the target-level array
+                if ((nh_total + nh) * sizeof(mimeo_hsp) > g_all_hsps.cap) {
+                    DeviceBuf bigger;
+                    if ((rc = bigger.reserve((nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) break;
+                    if (nh_total) HIP_TRY(hipMemcpyAsync(bigger.p, g_all_hsps.p, nh_total * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    g_all_hsps.release();
+                    g_all_hsps = bigger;
+                }
+                if (nh) HIP_TRY(hipMemcpyAsync((char *)g_all_hsps.p + nh_total * sizeof(mimeo_hsp), g_unit_hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
+                Group g;
+                memset(&g, 0, sizeof g);
+                g.T = tv; g.Q = qv; g.tid = tid; g.qid = qid; g.minus = (uint32_t)minus;
+                g.hsp_begin = nh_total; g.hsp_end = nh_total + nh;
+                groups.push_back(g);
+                group_pair.push_back(ord[k]);
+                nh_total += nh;
+                g_stats.pair_strands++;
+                g_stats.seed_hits += nhits;
+                g_stats.hsps += nh;
+                g_stats.query_bases_scanned += qs.len;
+                g_stats.scan_bytes_algorithmic += scan_bytes_algorithmic(qs.len, nhits);
+                g_stats.scan_bytes_kernel += scan_bytes_kernel(ti.n, qi.n, nhits);
+                g_stats.scan_launches++;
+            }
+        }
+        if (rc) break;
+        if (nh_total && !groups.empty()) {
+            if ((rc = g_groups.reserve(groups.size() * sizeof(Group)))) break;
+            if ((rc = g_aln.reserve(nh_total * sizeof(mimeo_alignment)))) break;
+            HIP_TRY(hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st));
+            if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_all_hsps.p,
+                                          nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain, &ms_gapped)))
+                break;
+            HIP_TRY(hipMemcpy(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost));
+            std::vector<mimeo_alignment> host_aln(nh_total);
+            HIP_TRY(hipMemcpy(host_aln.data(), g_aln.p, nh_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost));
+            for (size_t gi = 0; gi < groups.size(); gi++) {
+                const Group &g = groups[gi];
+                if (g.overflow) {
+                    set_error("gapped extension band wider than the LDS ring (RING columns): not supported yet");
+                    rc = MIMEO_ERR_LIMIT;
+                    break;
+                }
+                g_stats.chained_hsps += g.nchain;
+                auto &dst = per_pair[group_pair[gi]];
+                dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
+            }
+        }
+        pos = end;
+    }
+    cache.clear();
+    if (rc) return rc;
+    uint64_t total = 0;
+    for (auto &v : per_pair) total += v.size();
+    mimeo_alignment *res = (mimeo_alignment *)malloc((total ? total : 1) * sizeof(mimeo_alignment));
+    if (!res) { set_error("host allocation failed"); return MIMEO_ERR_NOMEM; }
+    uint64_t w = 0;
+    for (auto &v : per_pair) { if (!v.empty()) memcpy(res + w, v.data(), v.size() * sizeof(mimeo_alignment)); w += v.size(); }
+    *out = res;
+    *nout = total;
+    g_stats.alignments = total;
+    g_stats.ms_index = cache.ms;
+    g_stats.ms_scan = tm.ms_count + tm.ms_fill;
+    g_stats.ms_scan_fill = tm.ms_fill;
+    g_stats.ms_extend = ms_ext;
+    g_stats.ms_chain = ms_chain;
+    g_stats.ms_gapped = ms_gapped;
+    g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+}  // namespace mimeo
