@@ -1,0 +1,96 @@
+"""Multi-GPU: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The path shards by TARGET scaffold: a target's seed index is built once on its owner
+and coverage is per target, so nothing is exchanged while aligning.  The only collective is one
+all-gatherv of the packed alignment records at the end (all_gather of counts, then all_gather of
+max-padded byte buffers — RCCL has no v-variant)."""
+import os
+
+import numpy as np
+
+
+class Dist:
+    def __init__(self):
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.backend = None
+        self._torch = None
+
+    def init(self, backend=None):
+        if self.world <= 1:
+            return self
+        import torch
+        import torch.distributed as td
+        self._torch = torch
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        self.backend = backend
+        if not td.is_initialized():
+            if backend == 'nccl':
+                torch.cuda.set_device(self.local_rank)
+            td.init_process_group(backend=backend)
+        return self
+
+    @property
+    def device(self):
+        if self.backend == 'nccl':
+            return self._torch.device('cuda', self.local_rank)
+        return 'cpu'
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as td
+            td.barrier()
+
+    def max_float(self, x):
+        """max over ranks of a python float (bench timing)."""
+        if self.world <= 1:
+            return x
+        import torch.distributed as td
+        t = self._torch.tensor([x], dtype=self._torch.float64, device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_int(self, x):
+        if self.world <= 1:
+            return int(x)
+        import torch.distributed as td
+        t = self._torch.tensor([int(x)], dtype=self._torch.int64, device=self.device)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return int(t.item())
+
+    def allgather_records(self, arr):
+        """Concatenate a structured numpy array over ranks, in rank order, on every rank."""
+        if self.world <= 1:
+            return arr
+        import torch.distributed as td
+        torch = self._torch
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        n = torch.tensor([raw.size], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        td.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(max(sizes), 1)
+        buf = torch.zeros(cap, dtype=torch.uint8, device=self.device)
+        if raw.size:
+            buf[:raw.size] = torch.from_numpy(raw.copy()).to(self.device)
+        outs = [torch.zeros(cap, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+        td.all_gather(outs, buf)
+        parts = [o[:s].cpu().numpy().view(arr.dtype) for o, s in zip(outs, sizes)]
+        return np.concatenate(parts) if parts else arr
+
+
+def shard_pairs_by_target(pairs, cost_of_target, world, rank):
+    """Longest-processing-time assignment of target scaffolds to ranks; returns this rank's
+    pairs in their original order.  `cost_of_target[t]` ~ Lt * sum of its query lengths."""
+    if world <= 1:
+        return list(pairs)
+    targets = sorted({t for t, _ in pairs}, key=lambda t: (-cost_of_target[t], t))
+    load = [0] * world
+    owner = {}
+    for t in targets:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[t] = r
+        load[r] += cost_of_target[t]
+    return [(t, q) for t, q in pairs if owner[t] == rank]

@@ -1,0 +1,151 @@
+"""Host-side text stages of the mimeo hot path: what run_jobs.sh does with sed/awk/sort around the
+lastz and bedtools calls.  Every function cites the reference command text it reproduces (paths
+relative to /root/reference/src/mimeo); the engine (HIP) supplies the numbers, these functions
+supply the bytes.
+"""
+import os
+import re
+
+import numpy as np
+
+TAB_HEADER = '#name1\tstrand1\tstart1\tend1\tname2\tstrand2\tstart2+\tend2+\tscore\tidentity'  # wrappers.py:996
+GFF_HEADER = '##gff-version 3\n#seqid\tsource\ttype\tstart\tend\tscore\tstrand\tphase\tattributes'  # wrappers.py:1153
+
+
+def read_fasta(path):
+    """FASTA -> (ids, [uint8 arrays]).  id = first word of the header, like Biopython's rec.id
+    used by the reference (utils.py:307, :549)."""
+    names, seqs, cur = [], [], None
+    with open(path, 'rb') as f:
+        data = f.read()
+    for block in data.split(b'>')[1:]:
+        nl = block.find(b'\n')
+        header = block if nl < 0 else block[:nl]
+        body = b'' if nl < 0 else block[nl + 1:]
+        names.append(header.split()[0].decode() if header.split() else '')
+        seqs.append(np.frombuffer(body.translate(None, b'\n\r \t'), dtype=np.uint8))
+    return names, seqs
+
+
+def read_fasta_dir(dirname):
+    """All records of all files in a directory, like chromlens/get_all_pairs glob the split
+    directory (utils.py:92-102, :529-531); files are visited in sorted order."""
+    names, seqs = [], []
+    for fn in sorted(os.listdir(dirname)):
+        p = os.path.join(dirname, fn)
+        if os.path.isfile(p):
+            n, s = read_fasta(p)
+            names += n
+            seqs += s
+    return names, seqs
+
+
+def check_unique(names):
+    """utils.py:300-306 / :472-499: duplicate sequence ids are fatal."""
+    seen = set()
+    for n in names:
+        if n in seen:
+            raise SystemExit('Non-unique name in genome: %s. Quitting.' % n)
+        seen.add(n)
+
+
+def chromlens(names, seqs, outfile=None):
+    """utils.py:502-557: (id, str(len)) sorted by id; optional `id\\tlen` file (bedtools -g)."""
+    lens = sorted(((n, str(len(s))) for n, s in zip(names, seqs)), key=lambda x: x[0])
+    if outfile:
+        with open(outfile, 'w') as f:
+            for n, l in lens:
+                f.write(n + '\t' + l + '\n')
+    return lens
+
+
+def identity_pct(n, d):
+    """lastz prints identity as `n/d` and `%.1f%%`; the reference strips the % (wrappers.py:1040)
+    and compares the printed one-decimal value with minIdt (wrappers.py:1052)."""
+    return '%.1f' % (100.0 * n / d) if d else '0.0'
+
+
+def tab_block(alns, tname, qname, min_len, min_idt):
+    """One pair's block of the 10-column TAB (wrappers.py:1043-1056):
+    awk '0+$5 >= minLen' | awk '0+$13 >= minIdt {print $1,$2,$3,$4,$6,$7,$8,$9,$11,$13}' |
+    sort -k 1,1 -k 3n,4n.  `alns` are engine records of ONE (target, query) pair; start1 and
+    start2+ are origin-one (lastz general format), ends inclusive == half-open end."""
+    rows = []
+    for a in alns:
+        ts, te = int(a['tstart']), int(a['tend'])
+        if te - ts < min_len:  # length1 = end1 - start1 + 1 = te - ts
+            continue
+        pct = identity_pct(int(a['id_n']), int(a['id_d']))
+        if float(pct) < min_idt:
+            continue
+        line = '\t'.join([tname, '+', str(ts + 1), str(te), qname, '-' if int(a['qstrand']) else '+',
+                          str(int(a['qstart']) + 1), str(int(a['qend'])), str(int(a['score'])), pct])
+        rows.append((ts + 1, line.encode(), line))
+    rows.sort(key=lambda r: (r[0], r[1]))  # name1 is constant inside a block
+    return [r[2] for r in rows]
+
+
+def parse_tab(path):
+    """Read a 10-column TAB (ours, or imported from another aligner: README.md:329-347)."""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            if not line.strip() or line.startswith('#'):
+                continue
+            rows.append(line.split())
+    return rows
+
+
+def _awk_num(s):
+    m = re.match(r'\s*[-+]?(\d+\.?\d*([eE][-+]?\d+)?|\.\d+([eE][-+]?\d+)?)', s)
+    return float(m.group(0)) if m else 0.0
+
+
+def bed_intervals(tab_rows, chrom_ids):
+    """wrappers.py:1120-1128: awk '{print $1,$3,$4}' — BED start is the origin-one start1,
+    un-shifted.  Returns an (n,3) uint32 array of (chrom id, start, end);
+    rows on unknown chromosomes are dropped (bedtools genomecov would reject them)."""
+    out = []
+    for f in tab_rows:
+        c = chrom_ids.get(f[0])
+        if c is None:
+            continue
+        s, e = int(_awk_num(f[2])), int(_awk_num(f[3]))
+        if s < 0 or e < 0:
+            continue
+        out.append((c, s, e))
+    return np.array(out, dtype=np.uint32).reshape(-1, 3)
+
+
+def gff_repeat_lines(regions, names_sorted, source, label, prefix):
+    """wrappers.py:1166-1177 (self, source 'mimeo-self') / :883-894 (x, source 'mimeo'): one
+    row per region in (chrom, start) order, ID = prefix_%05d counting from 1."""
+    lines = []
+    for i, r in enumerate(regions, 1):
+        lines.append('\t'.join([names_sorted[int(r['chrom'])], source, label, str(int(r['start'])), str(int(r['end'])),
+                                '.', '+', '.', 'ID=%s_%05d' % (prefix, i)]))
+    return lines
+
+
+def import_align(tab_rows, prefix=None, min_len=100, min_idt=95):
+    """wrappers.py:33-117 import_Align: re-filter on int(end)-int(start) and float(pID); sort on
+    the STRING columns tName, tStart, tEnd, tStrand (lexicographic, stable); UID = prefix_<rank>
+    zero-padded to the width of the hit count.  Exits 1 when nothing passes (wrappers.py:94-96)."""
+    hits = [f[:10] for f in tab_rows if int(f[3]) - int(f[2]) >= min_len and float(f[9]) >= min_idt]
+    if not hits:
+        raise SystemExit(1)
+    hits.sort(key=lambda f: (f[0], f[2], f[3], f[1]))
+    width = len(str(len(hits)))
+    pre = str(prefix) if prefix else 'BHit'
+    return [f + ['%s_%s' % (pre, str(i).zfill(width))] for i, f in enumerate(hits, 1)]
+
+
+def gff_map_lines(rows, chrlens=None, ftype='BHit'):
+    """wrappers.py:443-522 writeGFFlines (source mimeo-map, ##sequence-region per chromosome)."""
+    yield '##gff-version 3\n'
+    for name, maxlen in chrlens or []:
+        yield ' '.join(['##sequence-region', str(name), '1', str(maxlen) + '\n'])
+    yield '\t'.join(['##seqid', 'source', 'type', 'start', 'end', 'score', 'strand', 'phase', 'attributes' + '\n'])
+    for r in rows:
+        attributes = ';'.join(['ID=' + r[10], 'identity=' + str(r[9]), 'B_locus=' + r[4] + '_' + r[5] + '_' + str(r[6]) + '_' + str(r[7])])
+        yield '\t'.join([r[0], 'mimeo-map', ftype, str(r[2]), str(r[3]), str(r[8]), r[1], '.', attributes + '\n'])

@@ -1,0 +1,66 @@
+"""`mimeo map` — all high-identity segments shared between genomes (reference:
+src/mimeo/run_map.py:190-328)."""
+import argparse
+import logging
+import os
+import sys
+
+from . import _cli, engine, formats, workflow
+
+
+def mainArgs(argv=None):
+    parser = argparse.ArgumentParser(
+        description='Find all high-identity segments shared between genomes.', prog='mimeo-map')
+    _cli.add_common(parser, 'mimeo-map', None, 'BHit', 'BHit', with_b=True)
+    parser.add_argument('--TRFpath', type=str, default='trf', help='Accepted for compatibility; TRF is not used.')
+    for name, default in (('tmatch', 2), ('tmismatch', 7), ('tdelta', 7), ('tPM', 80), ('tPI', 10), ('tminscore', 50),
+                          ('tmaxperiod', 50)):
+        parser.add_argument('--' + name, type=int, default=default, help='TRF parameter (tandem filter).')
+    parser.add_argument('--maxtandem', type=float, default=None,
+                        help='Max percentage of an A-genome alignment which may be masked by TRF.')
+    parser.add_argument('--writeTRF', action='store_true', default=False, help='Write TRF-filtered alignment file.')
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = mainArgs(argv)
+    dist, outdir = _cli.start(args)
+    logging.info('Starting genome mapping workflow.')
+    if args.maxtandem:
+        # reference: wrappers.py:120-262 trfFilter runs the external TRF binary.  The on-GPU
+        # tandem scorer that replaces it is SURVEY §8(f)-1 ("next"); refuse rather than skip silently.
+        logging.error('--maxtandem needs the tandem scorer, which is not part of this build yet.')
+        sys.exit(1)
+    an, aseq = _cli.load_genome(args.afasta, args.adir, 'A')
+    bn, bseq = _cli.load_genome(args.bfasta, args.bdir, 'B')
+    outtab = os.path.join(outdir, args.outfile)
+    chrLens = formats.chromlens(an, aseq)  # run_map.py:255 (no file)
+    A, B = engine.Genome(an, aseq), engine.Genome(bn, bseq)
+    pairs = workflow.all_pairs(len(an), len(bn))
+    if not pairs:
+        logging.error('No files to align. Check --adir and --bdir contain at least one fasta each.')
+        sys.exit(1)
+    workflow.map_hits(A, B, pairs, outtab, minIdt=args.minIdt, minLen=args.minLen, hspthresh=args.hspthresh,
+                      reuseTab=args.recycle, dist=dist)
+    if dist.rank == 0:
+        logging.info('Importing alignments from %s' % outtab)
+        rows = formats.parse_tab(outtab)
+        if not rows:
+            logging.warning('No alignments found in %s' % outtab)
+            sys.exit(1)
+        rows = formats.import_align(rows, prefix=args.prefix, min_len=args.minLen, min_idt=args.minIdt)
+        if args.gffout:
+            gffout = os.path.join(outdir, args.gffout)
+            logging.info('Writing GFF3 output to %s' % gffout)
+            with open(gffout, 'w') as f:
+                for x in formats.gff_map_lines(rows, chrlens=chrLens, ftype=args.label):
+                    f.write(x)
+    if args.verbose:
+        logging.info('engine stats: %s', engine.stats())
+    A.close()
+    B.close()
+    logging.info('Finished!')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,117 @@
+"""The three mimeo workflows with the shell pipeline replaced by engine calls.
+
+Mirrors the reference's command builders + executor:
+  self_repeats  <- wrappers.py:899-1271 self_LZ_cmds   + utils.py:213-254 run_cmd
+  x_repeats     <- wrappers.py:683-896  xspecies_LZ_cmds
+  map_hits      <- wrappers.py:525-680  map_LZ_cmds, :33-117 import_Align, :443-522 writeGFFlines
+Same argument names and meaning as those functions where they still apply; `lzpath` /
+`bdtlsPath` are gone because no external tool is run.
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import engine, formats
+from .dist import Dist, shard_pairs_by_target
+
+
+def all_pairs(n_a, n_b=None):
+    """utils.py:65-106 get_all_pairs: full ordered Cartesian product; self mode includes (A,A)
+    and both orders.  The reference inherits the order of glob(); here it is FASTA order."""
+    if n_b is None:
+        return [(a, b) for a in range(n_a) for b in range(n_a)]
+    return [(a, b) for a in range(n_a) for b in range(n_b)]
+
+
+def align_blocks(A, B, pairs, params, min_len, min_idt, dist=None):
+    """Align every pair (sharded by target over ranks when dist.world > 1) and return
+    {(t, q): [TAB lines]} on every rank, plus the raw record count."""
+    dist = dist or Dist()
+    QG = B if B is not None else A
+    if dist.world > 1:
+        qsum = {}
+        for t, q in pairs:
+            qsum[t] = qsum.get(t, 0) + QG.lengths[q]
+        cost = {t: A.lengths[t] * s for t, s in qsum.items()}
+        mine = shard_pairs_by_target(pairs, cost, dist.world, dist.rank)
+    else:
+        mine = list(pairs)
+    alns = engine.align_pairs(A, B, mine, params) if mine else np.zeros(0, dtype=engine._ffi.ALIGNMENT)
+    alns = dist.allgather_records(alns)
+    blocks = {}
+    if alns.size:
+        key = alns['tid'].astype(np.int64) << 32 | alns['qid'].astype(np.int64)
+        order = np.argsort(key, kind='stable')
+        ks = key[order]
+        cuts = np.flatnonzero(np.diff(ks)) + 1
+        for seg in np.split(order, cuts):
+            t, q = int(alns['tid'][seg[0]]), int(alns['qid'][seg[0]])
+            blocks[(t, q)] = formats.tab_block(alns[seg], A.names[t], QG.names[q], min_len, min_idt)
+    return blocks, int(alns.size)
+
+
+def write_tab(path, pairs, blocks, select=None):
+    """Header + one sorted block per pair, appended in pair order (wrappers.py:996, :1056)."""
+    with open(path, 'w') as f:
+        f.write(formats.TAB_HEADER + '\n')
+        for pr in pairs:
+            if select is not None and not select(pr):
+                continue
+            for line in blocks.get(pr, ()):  # a pair without surviving rows adds nothing
+                f.write(line + '\n')
+
+
+def collapse_to_gff(tab_path, names, lengths, min_cov, min_len, source, label, prefix):
+    """wrappers.py:1116-1177: TAB -> BED -> depth >= minCov -> merge -> minLen -> GFF rows."""
+    names_sorted = sorted(names, key=lambda s: s.encode())
+    cid = {n: i for i, n in enumerate(names_sorted)}
+    length_of = dict(zip(names, lengths))
+    iv = formats.bed_intervals(formats.parse_tab(tab_path), cid)
+    if iv.shape[0] == 0:
+        return []
+    regions = engine.coverage_collapse(iv, [length_of[n] for n in names_sorted], min_cov, min_len)
+    return formats.gff_repeat_lines(regions, names_sorted, source, label, prefix)
+
+
+def self_repeats(A, pairs, outtab, outgff, minIdt=60, minLen=100, hspthresh=3000, minCov=3, intraCov=5,
+                 splitSelf=False, reuseTab=False, label='Self_repeats', prefix=None, dist=None, source='mimeo-self',
+                 B=None):
+    """`mimeo self` (and, with B and source='mimeo', `mimeo x`)."""
+    dist = dist or Dist()
+    outtab_intra = outtab + '_intra.tab'
+    if not reuseTab or not os.path.isfile(outtab):
+        params = engine.default_params(hspthresh=hspthresh)
+        blocks, _ = align_blocks(A, B, pairs, params, minLen, minIdt, dist)
+        if dist.rank == 0:
+            if splitSelf:
+                write_tab(outtab, pairs, blocks, select=lambda pr: pr[0] != pr[1])
+                write_tab(outtab_intra, pairs, blocks, select=lambda pr: pr[0] == pr[1])
+            else:
+                write_tab(outtab, pairs, blocks)
+    if dist.rank != 0:
+        return None
+    lines = collapse_to_gff(outtab, A.names, A.lengths, minCov, minLen, source, str(label), str(prefix))
+    if splitSelf:
+        if reuseTab and not os.path.isfile(outtab_intra) and os.path.isfile(outtab):
+            logging.warning("Warning: Could not find intra-chrom results file: %s \nRe-run in '--strictSelf' "
+                            "mode if required." % outtab_intra)
+        else:
+            # the reference restarts the ID counter with the same prefix (wrappers.py:1259-1264)
+            lines += collapse_to_gff(outtab_intra, A.names, A.lengths, intraCov, minLen, source,
+                                     str(label) + '_intra', str(prefix))
+    with open(outgff, 'w') as f:
+        f.write(formats.GFF_HEADER + '\n')
+        for line in lines:
+            f.write(line + '\n')
+    return lines
+
+
+def map_hits(A, B, pairs, outtab, minIdt=95, minLen=100, hspthresh=3000, reuseTab=False, dist=None):
+    """`mimeo map` alignment stage (wrappers.py:525-680): TAB only, no coverage collapse."""
+    dist = dist or Dist()
+    if not reuseTab or not os.path.isfile(outtab):
+        params = engine.default_params(hspthresh=hspthresh)
+        blocks, _ = align_blocks(A, B, pairs, params, minLen, minIdt, dist)
+        if dist.rank == 0:
+            write_tab(outtab, pairs, blocks)

@@ -1,0 +1,83 @@
+"""N>1 path on CPU: target sharding and the all-gatherv of alignment records over gloo with
+world_size 2 (the GPU path uses the same code over RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_pairs_by_target_covers_everything_once():
+    from mimeo_amd.dist import shard_pairs_by_target
+    pairs = [(t, q) for t in range(7) for q in range(7)]
+    cost = {t: (t + 1) * 10 for t in range(7)}
+    for world in (1, 2, 3, 8):
+        shards = [shard_pairs_by_target(pairs, cost, world, r) for r in range(world)]
+        flat = sorted(p for s in shards for p in s)
+        assert flat == sorted(pairs)
+        for s in shards:  # a target never splits across ranks
+            for other in shards:
+                if s is not other:
+                    assert not ({t for t, _ in s} & {t for t, _ in other})
+    two = [shard_pairs_by_target(pairs, cost, 2, r) for r in range(2)]
+    loads = [sum(cost[t] for t in {t for t, _ in s}) for s in two]
+    assert abs(loads[0] - loads[1]) <= max(cost.values())
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from mimeo_amd import _ffi
+    from mimeo_amd.dist import Dist
+    d = Dist().init('gloo')
+    rng = np.random.default_rng(d.rank)
+    n = [3, 0][d.rank] if os.environ.get('EMPTY_RANK1') else 5 + 4 * d.rank
+    a = np.zeros(n, dtype=_ffi.ALIGNMENT)
+    a['tid'] = d.rank
+    a['tstart'] = np.arange(n)
+    a['score'] = 1000 * (d.rank + 1) + np.arange(n)
+    g = d.allgather_records(a)
+    exp_n = 3 if os.environ.get('EMPTY_RANK1') else 5 + 9
+    assert g.size == exp_n, g.size
+    assert list(g['tid'][: (3 if os.environ.get('EMPTY_RANK1') else 5)]) == [0] * (3 if os.environ.get('EMPTY_RANK1') else 5)
+    if not os.environ.get('EMPTY_RANK1'):
+        assert list(g['score'][5:]) == [2000 + i for i in range(9)]
+    assert d.max_float(float(d.rank)) == 1.0 and d.sum_int(d.rank + 1) == 3
+    d.barrier()
+    print('rank', d.rank, 'ok')
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_world2(extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, '-c', WORKER % ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_allgather_records_gloo_world2():
+    _run_world2()
+
+
+def test_allgather_records_with_empty_rank():
+    _run_world2({'EMPTY_RANK1': '1'})

@@ -1,0 +1,123 @@
+"""End to end: `mimeo self | x | map` through the HIP engine must write byte-identical TAB / GFF3
+to the oracle pipeline (C alignment oracle -> Python restatement of the reference's text stages)."""
+import os
+
+import numpy as np
+import pytest
+
+from mimeo_amd.synth import make_families, synth_genome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mimeo_amd import engine
+    engine.init(0)
+    return engine
+
+
+def _oracle_tab(an, aseq, bn, bseq, pairs, min_len, min_idt, select=None):
+    from oracle import oracle as O, pipeline as P
+    lines = ['#name1\tstrand1\tstart1\tend1\tname2\tstrand2\tstart2+\tend2+\tscore\tidentity']
+    for t, q in pairs:
+        if select and not select((t, q)):
+            continue
+        al = O.align_pair(aseq[t].tobytes(), bseq[q].tobytes())
+        al['tid'], al['qid'] = t, q
+        text = '\n'.join(P.general_rows(an, bn, [len(s) for s in bseq], al)) + '\n'
+        lines += P.filter_project_sort(text, min_len, min_idt)
+    return lines
+
+
+def _oracle_gff(tab_lines, names, seqs, cov, min_len, source, label, prefix):
+    from oracle import pipeline as P
+    bed = P.bed_project_sort(tab_lines)
+    iv = [(l.split('\t')[0], int(l.split('\t')[1]), int(l.split('\t')[2])) for l in bed]
+    regs = P.coverage_collapse(iv, {n: len(s) for n, s in zip(names, seqs)}, cov, min_len)
+    return P.gff_self_lines(regs, label, prefix, source=source)
+
+
+def test_self_workflow_files_match_oracle(eng, tmp_path):
+    from mimeo_amd import workflow
+    names, seqs = synth_genome(50, 300_000, 3, repeat_frac=0.2, families=3, cons_len=(300, 1500), max_div=0.1)
+    names = ['s2', 's10', 's1']  # C-locale order differs from FASTA order
+    A = eng.Genome(names, seqs)
+    pairs = workflow.all_pairs(3)
+    outtab, outgff = str(tmp_path / 'o.tab'), str(tmp_path / 'o.gff3')
+    workflow.self_repeats(A, pairs, outtab, outgff, minIdt=80, minLen=100, minCov=3, label='Self_Repeat', prefix='Self_Repeat')
+    exp_tab = _oracle_tab(names, seqs, names, seqs, pairs, 100, 80)
+    assert open(outtab).read() == '\n'.join(exp_tab) + '\n'
+    exp_gff = _oracle_gff(exp_tab, names, seqs, 3, 100, 'mimeo-self', 'Self_Repeat', 'Self_Repeat')
+    assert len(exp_gff) > 2
+    assert open(outgff).read() == '\n'.join(exp_gff) + '\n'
+    # --recycle re-enters at the collapse with the same result
+    os.remove(outgff)
+    workflow.self_repeats(A, pairs, outtab, outgff, minIdt=80, minLen=100, minCov=3, reuseTab=True, label='Self_Repeat', prefix='Self_Repeat')
+    assert open(outgff).read() == '\n'.join(exp_gff) + '\n'
+    A.close()
+
+
+def test_strict_self_workflow(eng, tmp_path):
+    from mimeo_amd import workflow
+    names, seqs = synth_genome(52, 200_000, 2, repeat_frac=0.25, families=2, cons_len=(300, 1200), max_div=0.08)
+    A = eng.Genome(names, seqs)
+    pairs = workflow.all_pairs(2)
+    outtab, outgff = str(tmp_path / 'o.tab'), str(tmp_path / 'o.gff3')
+    workflow.self_repeats(A, pairs, outtab, outgff, minIdt=60, minLen=100, minCov=2, intraCov=1, splitSelf=True,
+                          label='SR', prefix='SR')
+    inter = _oracle_tab(names, seqs, names, seqs, pairs, 100, 60, select=lambda p: p[0] != p[1])
+    intra = _oracle_tab(names, seqs, names, seqs, pairs, 100, 60, select=lambda p: p[0] == p[1])
+    assert open(outtab).read() == '\n'.join(inter) + '\n'
+    assert open(outtab + '_intra.tab').read() == '\n'.join(intra) + '\n'
+    g1 = _oracle_gff(inter, names, seqs, 2, 100, 'mimeo-self', 'SR', 'SR')
+    g2 = _oracle_gff(intra, names, seqs, 1, 100, 'mimeo-self', 'SR_intra', 'SR')
+    assert open(outgff).read() == '\n'.join(g1 + g2[2:]) + '\n'
+    A.close()
+
+
+def test_x_and_map_workflows(eng, tmp_path):
+    from mimeo_amd import formats, workflow
+    from oracle import pipeline as P
+    fams = make_families(77, 3, (300, 1500))
+    an, aseq = synth_genome(61, 200_000, 2, repeat_frac=0.2, shared_families=fams, prefix='a')
+    bn, bseq = synth_genome(62, 200_000, 2, repeat_frac=0.2, shared_families=fams, prefix='b')
+    A, B = eng.Genome(an, aseq), eng.Genome(bn, bseq)
+    pairs = workflow.all_pairs(2, 2)
+    outtab, outgff = str(tmp_path / 'x.tab'), str(tmp_path / 'x.gff3')
+    workflow.self_repeats(A, pairs, outtab, outgff, minIdt=60, minLen=100, minCov=2, label='B_Repeat', prefix='B_Repeat',
+                          source='mimeo', B=B)
+    exp_tab = _oracle_tab(an, aseq, bn, bseq, pairs, 100, 60)
+    assert open(outtab).read() == '\n'.join(exp_tab) + '\n'
+    exp_gff = _oracle_gff(exp_tab, an, aseq, 2, 100, 'mimeo', 'B_Repeat', 'B_Repeat')
+    assert open(outgff).read() == '\n'.join(exp_gff) + '\n'
+    # map: TAB then import_Align + GFF
+    maptab = str(tmp_path / 'm.tab')
+    workflow.map_hits(A, B, pairs, maptab, minIdt=90, minLen=100)
+    exp_map = _oracle_tab(an, aseq, bn, bseq, pairs, 100, 90)
+    assert open(maptab).read() == '\n'.join(exp_map) + '\n'
+    rows = formats.import_align(formats.parse_tab(maptab), 'HGT', 100, 90)
+    got = ''.join(formats.gff_map_lines(rows, formats.chromlens(an, aseq), 'BHit'))
+    orows = P.import_align('\n'.join(exp_map), 'HGT', 100, 90)
+    assert got == '\n'.join(P.gff_map_lines(orows, formats.chromlens(an, aseq), 'BHit')) + '\n'
+    A.close()
+    B.close()
+
+
+def test_cli_self_end_to_end(eng, tmp_path):
+    """`python -m mimeo_amd self --afasta ...` writes the three reference outputs."""
+    import subprocess
+    import sys
+    from mimeo_amd.synth import write_fasta
+    names, seqs = synth_genome(53, 160_000, 2, repeat_frac=0.2, families=2, cons_len=(300, 1200))
+    fa = str(tmp_path / 'g.fa')
+    write_fasta(fa, names, seqs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'mimeo_amd', 'self', '--afasta', fa, '-d', str(tmp_path / 'out'), '--minIdt', '80',
+                        '--minLen', '100', '--minCov', '2'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = tmp_path / 'out'
+    assert (out / 'A_gen_lens.txt').read_text() == ''.join('%s\t%d\n' % (n, len(s)) for n, s in zip(names, seqs))
+    exp_tab = _oracle_tab(names, seqs, names, seqs, [(a, b) for a in range(2) for b in range(2)], 100, 80)
+    assert (out / 'mimeo_alignment.tab').read_text() == '\n'.join(exp_tab) + '\n'
+    assert (out / 'mimeo-self_repeats.gff3').read_text().startswith('##gff-version 3\n#seqid\tsource')
