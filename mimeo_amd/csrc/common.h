@@ -111,14 +111,24 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms);
 
 // K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
+constexpr int MAX_BATCH = 32;
 struct Group {
     StrandView T, Q;
     uint32_t tid, qid, minus, nchain;
     uint64_t hsp_begin, hsp_end;
     uint32_t naln, overflow;
+    // K6 round state: anchors are taken in order, up to nbatch per round
+    uint32_t next, nacc, nbatch, job0;
+    uint32_t batch[MAX_BATCH];
 };
-// chain + gapped extension of every group; alignments of group g land at d_aln[hsp_begin ..
-// hsp_begin + naln) (k5_chain_gapped.hip)
+// K5 (k5_chain.hip): sort + chain + anchor order for every group
+int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps, int do_chain,
+                 mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order);
+// K6 (k6_gapped.hip): anchors -> gapped alignments; alignments of group g land at
+// d_aln[hsp_begin .. hsp_begin + naln)
+int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
+                  uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln);
+// chain + gapped extension of every group (pipeline.hip)
 int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps,
                         const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,
                         float *ms_gapped);

@@ -1,0 +1,117 @@
+// K5 — lastz `--chain` (reference call site src/mimeo/wrappers.py:1031 `--chain`).
+//
+// Work unit = one group = one (target scaffold, query scaffold, strand); one workgroup owns it:
+//   * rank-sort the group's HSPs by (tstart, qstart, length);
+//   * chain DP  best[j] = score[j] + max(0, max{best[i] : i ends at or before the start of j in both
+//     sequences}), evaluated forward (when j is final every later compatible k is relaxed), ties
+//     to the earliest predecessor and the earliest chain end;
+//   * flag the chain and order the chained HSPs by (score desc, tstart, qstart, length) — the
+//     order in which K6 turns them into anchors.
+#include "device_util.h"
+
+namespace mimeo {
+
+constexpr int CH_THREADS = 256;
+
+__device__ __forceinline__ bool hsp_less(const mimeo_hsp &a, const mimeo_hsp &b) {
+    if (a.tstart != b.tstart) return a.tstart < b.tstart;
+    if (a.qstart != b.qstart) return a.qstart < b.qstart;
+    return a.length < b.length;
+}
+// anchor order: score descending, then (tstart, qstart, length)
+__device__ __forceinline__ bool anchor_less(const mimeo_hsp &a, const mimeo_hsp &b) {
+    if (a.score != b.score) return a.score > b.score;
+    return hsp_less(a, b);
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ groups, const mimeo_hsp *__restrict__ in,
+                                                       mimeo_hsp *__restrict__ hs, long long *__restrict__ best,
+                                                       long long *__restrict__ cand, int *__restrict__ pred,
+                                                       uint32_t *__restrict__ order, int do_chain) {
+    Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    const uint32_t n = (uint32_t)(G.hsp_end - G.hsp_begin);
+    const uint32_t tid = threadIdx.x;
+    __shared__ long long s_best[CH_THREADS / 64];
+    __shared__ uint32_t s_idx[CH_THREADS / 64];
+    __shared__ uint32_t s_m;
+    if (n == 0) { if (tid == 0) G.nchain = 0; return; }
+    // 1. rank sort into hs[b0 .. b0+n)
+    for (uint32_t i = tid; i < n; i += CH_THREADS) {
+        mimeo_hsp me = in[b0 + i];
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            mimeo_hsp o = in[b0 + k];
+            if (hsp_less(o, me) || (!hsp_less(me, o) && k < i)) rank++;
+        }
+        me.flags = 0;
+        hs[b0 + rank] = me;
+    }
+    __syncthreads();
+    if (do_chain) {
+        for (uint32_t k = tid; k < n; k += CH_THREADS) { cand[b0 + k] = 0; pred[b0 + k] = -1; }
+        __syncthreads();
+        for (uint32_t j = 0; j < n; j++) {
+            mimeo_hsp hj = hs[b0 + j];
+            long long bj = cand[b0 + j] + hj.score;
+            if (tid == 0) best[b0 + j] = bj;
+            uint32_t te = hj.tstart + hj.length, qe = hj.qstart + hj.length;
+            // relax every later HSP that starts after hj ends (strict improvement keeps the earliest j)
+            uint32_t k0 = j + 1 + ((tid + CH_THREADS - ((j + 1) % CH_THREADS)) % CH_THREADS);
+            for (uint32_t k = k0; k < n; k += CH_THREADS) {
+                const mimeo_hsp &hk = hs[b0 + k];
+                if (te <= hk.tstart && qe <= hk.qstart && bj > cand[b0 + k]) { cand[b0 + k] = bj; pred[b0 + k] = (int)j; }
+            }
+            __syncthreads();
+        }
+        // argmax of best, earliest on ties
+        long long mb = INT64_MIN;
+        uint32_t mi = 0xFFFFFFFFu;
+        for (uint32_t k = tid; k < n; k += CH_THREADS) {
+            long long v = best[b0 + k];
+            if (v > mb) { mb = v; mi = k; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            long long ob = __shfl_xor(mb, o);
+            uint32_t oi = __shfl_xor(mi, o);
+            if (ob > mb || (ob == mb && oi < mi)) { mb = ob; mi = oi; }
+        }
+        if ((tid & 63) == 0) { s_best[tid >> 6] = mb; s_idx[tid >> 6] = mi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < CH_THREADS / 64; w++)
+                if (s_best[w] > mb || (s_best[w] == mb && s_idx[w] < mi)) { mb = s_best[w]; mi = s_idx[w]; }
+            uint32_t m = 0;
+            for (int k = (int)mi; k >= 0; k = pred[b0 + k]) { hs[b0 + k].flags = 1; m++; }
+            s_m = m;
+        }
+        __syncthreads();
+    } else {
+        for (uint32_t k = tid; k < n; k += CH_THREADS) hs[b0 + k].flags = 1;
+        if (tid == 0) s_m = n;
+        __syncthreads();
+    }
+    // 2. anchor order of the flagged HSPs (rank among flagged by anchor_less)
+    for (uint32_t i = tid; i < n; i += CH_THREADS) {
+        mimeo_hsp me = hs[b0 + i];
+        if (!(me.flags & 1u)) continue;
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            const mimeo_hsp &o = hs[b0 + k];
+            if ((o.flags & 1u) && k != i && anchor_less(o, me)) rank++;
+        }
+        order[b0 + rank] = i;
+    }
+    if (tid == 0) G.nchain = s_m;
+}
+
+int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps, int do_chain,
+                 mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order) {
+    if (!ngroups || !nhsps) return 0;
+    hipLaunchKernelGGL(k5_chain, dim3(ngroups), dim3(CH_THREADS), 0, stream(), d_groups, d_hsps, d_sorted, d_best,
+                       d_cand, d_pred, d_order, do_chain);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mimeo

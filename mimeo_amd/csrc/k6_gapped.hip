@@ -1,0 +1,437 @@
+// K6 — lastz `--gapped` (reference call site src/mimeo/wrappers.py:1031):
+// every chained HSP becomes an anchor (centre of its best 31-column window); anchors are taken
+// by decreasing HSP score, an anchor that lies inside the box of an earlier alignment is
+// skipped, every other anchor is extended in both directions by a y-drop affine-gap DP
+// (gap open 400 / extend 30, y-drop 9400) and the two halves are joined.
+//
+// Decomposition:
+//   * a half extension is one JOB executed by one wavefront.  The DP is evaluated row by row;
+//     lane l owns the 16-column strip (j / 16) % 64 == l of a 1024-column window that slides with
+//     the first live column, all state (score + match/mismatch counts of the C and D planes) in
+//     registers.  Inside a row the only horizontal dependency is the insertion state, computed
+//     as a max-plus prefix scan of u_k = H_k + k*E (in-lane over the strip, then one cross-lane
+//     scan).  Pruning: a cell scoring below (best of the rows above) - ydrop is dead.  Cells carry
+//     (score, matches, mismatches), so identity needs no traceback.
+//   * exact shortcut: if the two sequences are identical and N-free from the anchor to the end of
+//     the shorter one, the diagonal is optimal (every column already scores its maximum) and the
+//     DP is skipped — this is what makes the trivial (A,A) self alignment cheap.
+//   * jobs of different anchors are independent, only the skip rule is ordered: each round takes
+//     the next <= nbatch unskipped anchors of every group (k6_pick), extends them all (k6_dp),
+//     then replays the skip rule in order over the batch (k6_resolve).
+#include "device_util.h"
+
+namespace mimeo {
+
+constexpr int32_t NEG = -(1 << 30);
+constexpr int32_t NEGH = -(1 << 29);
+constexpr int WSTRIP = 16;          // columns per lane
+constexpr int WINDOW = 64 * WSTRIP;  // columns in the sliding window
+constexpr uint32_t SMASK = (1u << WSTRIP) - 1u;
+constexpr int WSHIFT = 4;            // log2(WSTRIP)
+static_assert((1 << WSHIFT) == WSTRIP, "WSTRIP must be a power of two");
+
+struct Cell {
+    int32_t s;
+    uint32_t nm, nx;
+};
+struct HalfResult {
+    int32_t score;
+    uint32_t i, j, nm, nx, overflow;
+};
+struct DpJob {
+    uint32_t group, at, aq;
+    int32_t dir;
+};
+
+__device__ __forceinline__ Cell cmax_left(const Cell &l, const Cell &r) { return r.s > l.s ? r : l; }  // ties -> left
+__device__ __forceinline__ Cell shfl_cell(const Cell &c, int src) {
+    Cell o;
+    o.s = __shfl(c.s, src); o.nm = __shfl(c.nm, src); o.nx = __shfl(c.nx, src);
+    return o;
+}
+
+// WSTRIP query bits for columns jb .. jb+WSTRIP-1 (bit s <-> column jb+s); column j consumes query base
+// aq + j - 1 (dir > 0) or aq - j (dir < 0).  Out-of-range columns read padding and are never used.
+__device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int dir, uint32_t jb, uint32_t lenB,
+                                           uint32_t &qlo, uint32_t &qhi, uint32_t &qn) {
+    if (jb > lenB) { qlo = qhi = qn = 0; return; }
+    if (dir > 0) {
+        int32_t p = (int32_t)(aq + jb) - 1;
+        qlo = get32(Q.lo, p) & SMASK; qhi = get32(Q.hi, p) & SMASK; qn = get32(Q.nm, p) & SMASK;
+    } else {
+        // bit t <-> position p + t <-> column jb + WSTRIP - 1 - t
+        int32_t p = (int32_t)aq - (int32_t)jb - (WSTRIP - 1);
+        qlo = __brev(get32(Q.lo, p) & SMASK) >> (32 - WSTRIP); qhi = __brev(get32(Q.hi, p) & SMASK) >> (32 - WSTRIP);
+        qn = __brev(get32(Q.nm, p) & SMASK) >> (32 - WSTRIP);
+    }
+}
+
+// One-sided y-drop affine extension by one wavefront (all lanes return the same result).
+__device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq, int dir,
+                                       int32_t O, int32_t E, int32_t Y) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
+    HalfResult best{0, 0, 0, 0, 0, 0};
+    // ---- exact shortcut: identical, N-free to the end of the shorter sequence
+    {
+        const uint32_t n = min(lenA, lenB);
+        const int32_t st = dir > 0 ? (int32_t)at : (int32_t)(at - n), sq = dir > 0 ? (int32_t)aq : (int32_t)(aq - n);
+        bool ok = true;
+        uint64_t ncg = 0;
+        for (uint32_t k0 = 0; k0 < n; k0 += 64u * 32u) {
+            uint32_t k = k0 + lane * 32u;
+            if (k < n) {
+                uint32_t tlo = get32(T.lo, st + (int32_t)k), thi = get32(T.hi, st + (int32_t)k);
+                uint32_t bad = (tlo ^ get32(Q.lo, sq + (int32_t)k)) | (thi ^ get32(Q.hi, sq + (int32_t)k)) |
+                               get32(T.nm, st + (int32_t)k) | get32(Q.nm, sq + (int32_t)k);
+                uint32_t rem = n - k, mask = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+                if (bad & mask) ok = false;
+                ncg += __popc((tlo ^ thi) & mask);
+            }
+            if (__ballot(!ok)) break;
+        }
+        if (!__ballot(!ok)) {
+            for (int o = 32; o > 0; o >>= 1) ncg += __shfl_xor(ncg, o);
+            uint64_t sc = 100ull * ncg + 91ull * ((uint64_t)n - ncg);
+            best.score = (int32_t)sc; best.i = n; best.j = n; best.nm = n; best.nx = 0;
+            best.overflow = sc >= (1ull << 31) ? 1u : 0u;
+            return best;
+        }
+    }
+    // ---- general row-by-row DP
+    int32_t Cs[WSTRIP], Ds[WSTRIP];
+    uint32_t Cm[WSTRIP], Cx[WSTRIP], Dm[WSTRIP], Dx[WSTRIP];
+    uint32_t wb = 0, r = lane, jb = lane * WSTRIP;
+    uint32_t qlo, qhi, qn;
+    load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+    bool over = false;
+#pragma unroll
+    for (int s = 0; s < WSTRIP; s++) {
+        uint32_t j = jb + s;
+        int32_t v = j ? -O - (int32_t)j * E : 0;
+        bool alive = j <= lenB && (j == 0 || v >= -Y);
+        Cs[s] = alive ? v : NEG; Cm[s] = 0; Cx[s] = 0;
+        Ds[s] = NEG; Dm[s] = 0; Dx[s] = 0;
+        if (alive && j >= WINDOW - WSTRIP) over = true;
+    }
+    if (__ballot(over)) { best.overflow = 1; return best; }
+    for (uint32_t i = 1; i <= lenA; i++) {
+        const int32_t thr = best.score - Y;
+        const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
+        const uint32_t alo = getbit(T.lo, pa), ahi = getbit(T.hi, pa), an = getbit(T.nm, pa), acg = alo ^ ahi;
+        // C of the column left of my strip (previous row): last slot of the previous lane in ring order
+        Cell p7{Cs[WSTRIP - 1], Cm[WSTRIP - 1], Cx[WSTRIP - 1]};
+        p7 = shfl_cell(p7, (int)((lane + 63u) & 63u));
+        if (r == 0) p7.s = NEG;
+        // pass 1 (slots descending, in place): D(i,j) and H(i,j) = max(diagonal, D) overwrite the
+        // previous row's D and C; slot s still sees the old C of slot s-1
+#pragma unroll
+        for (int s = WSTRIP - 1; s >= 0; s--) {
+            const uint32_t j = jb + s;
+            const bool exists = j <= lenB;
+            Cell dd{NEG, 0, 0}, g{NEG, 0, 0};
+            if (Ds[s] > NEGH) { dd.s = Ds[s] - E; dd.nm = Dm[s]; dd.nx = Dx[s]; }
+            if (Cs[s] > NEGH && Cs[s] - O - E > dd.s) { dd.s = Cs[s] - O - E; dd.nm = Cm[s]; dd.nx = Cx[s]; }
+            Cell pc = s ? Cell{Cs[s ? s - 1 : 0], Cm[s ? s - 1 : 0], Cx[s ? s - 1 : 0]} : p7;
+            if (pc.s > NEGH && j >= 1) {
+                uint32_t dl = alo ^ ((qlo >> s) & 1u), dh = ahi ^ ((qhi >> s) & 1u), nn = an | ((qn >> s) & 1u);
+                bool m = !(dl | dh | nn);
+                g.s = pc.s + sub_score(dl, dh, acg, nn);
+                g.nm = pc.nm + (m ? 1u : 0u);
+                g.nx = pc.nx + (m ? 0u : 1u);
+            }
+            if (!exists) { dd.s = NEG; g.s = NEG; }
+            Ds[s] = dd.s; Dm[s] = dd.nm; Dx[s] = dd.nx;
+            Cell hh = g;  // diagonal preferred on ties
+            if (dd.s > g.s) hh = dd;
+            Cs[s] = hh.s; Cm[s] = hh.nm; Cx[s] = hh.nx;
+        }
+        // pass 2: insertion state = exclusive max-plus scan of u_k = H_k + (k - wb) * E along the
+        // row: lane aggregate, then one cross-lane scan in ring order
+        Cell run{NEG, 0, 0};
+#pragma unroll
+        for (int s = 0; s < WSTRIP; s++) {
+            Cell u{Cs[s] > NEGH ? Cs[s] + (int32_t)(r * WSTRIP + s) * E : NEG, Cm[s], Cx[s]};
+            run = cmax_left(run, u);
+        }
+        Cell inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Cell l = shfl_cell(inc, (int)((lane + 64u - (uint32_t)o) & 63u));
+            if (r >= (uint32_t)o) inc = cmax_left(l, inc);
+        }
+        Cell acc = shfl_cell(inc, (int)((lane + 63u) & 63u));  // best u of every column left of my strip
+        if (r == 0) acc = Cell{NEG, 0, 0};
+        // pass 3: C = max(H, I), prune, row statistics
+        uint32_t amask = 0;
+        int32_t bs = NEG;
+        uint32_t bj = 0xFFFFFFFFu, bm = 0, bx = 0;
+#pragma unroll
+        for (int s = 0; s < WSTRIP; s++) {
+            Cell hh{Cs[s], Cm[s], Cx[s]};
+            Cell I{NEG, acc.nm, acc.nx};
+            if (acc.s > NEGH) I.s = acc.s - O - (int32_t)(r * WSTRIP + s) * E;
+            Cell u{hh.s > NEGH ? hh.s + (int32_t)(r * WSTRIP + s) * E : NEG, hh.nm, hh.nx};
+            acc = cmax_left(acc, u);
+            Cell c = hh;  // H preferred over I on ties
+            if (I.s > c.s) c = I;
+            const bool alive = (jb + s <= lenB) && c.s >= thr && c.s > NEGH;
+            Cs[s] = alive ? c.s : NEG; Cm[s] = c.nm; Cx[s] = c.nx;
+            if (!alive) Ds[s] = NEG;
+            if (alive) {
+                amask |= 1u << s;
+                if (c.s > bs) { bs = c.s; bj = jb + s; bm = c.nm; bx = c.nx; }
+            }
+        }
+        const uint64_t ball = __ballot(amask != 0);
+        if (!ball) break;
+        const uint32_t base = (wb >> WSHIFT) & 63u;
+        const uint64_t rot = base ? (ball >> base) | (ball << (64 - base)) : ball;
+        const uint32_t rf = (uint32_t)__builtin_ctzll(rot), rl = 63u - (uint32_t)__builtin_clzll(rot);
+        if (rl == 63u) { best.overflow = 1; break; }
+        // best cell of the row: max score, then smallest column
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int32_t os = __shfl_xor(bs, o);
+            uint32_t oj = __shfl_xor(bj, o), om = __shfl_xor(bm, o), ox = __shfl_xor(bx, o);
+            if (os > bs || (os == bs && oj < bj)) { bs = os; bj = oj; bm = om; bx = ox; }
+        }
+        if (bs > best.score) { best.score = bs; best.i = i; best.j = bj; best.nm = bm; best.nx = bx; }
+        // slide the window so that it starts at the strip holding the first live column
+        const uint32_t fmask = (uint32_t)__shfl((int)amask, (int)((rf + base) & 63u));
+        const uint32_t plo = wb + rf * WSTRIP + (uint32_t)__builtin_ctz(fmask);
+        const uint32_t nwb = plo & ~(uint32_t)(WSTRIP - 1);
+        if (nwb != wb) {
+            wb = nwb;
+            r = (lane - ((wb >> WSHIFT) & 63u)) & 63u;
+            const uint32_t njb = wb + r * WSTRIP;
+            if (njb != jb) {  // this lane's strip left the window on the left: it re-enters on the right
+                jb = njb;
+                load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+#pragma unroll
+                for (int s = 0; s < WSTRIP; s++) { Cs[s] = NEG; Ds[s] = NEG; }
+            }
+        }
+    }
+    return best;
+}
+
+// best 31-column window of an HSP (wave-cooperative): offset of its centre
+__device__ uint32_t wave_anchor_offset(const StrandView &T, const StrandView &Q, const mimeo_hsp &h) {
+    const uint32_t Wn = 31;
+    if (h.length <= Wn) return h.length / 2;
+    const uint32_t lane = threadIdx.x & 63u, nw = h.length - Wn + 1;
+    const int32_t d = (int32_t)h.tstart - (int32_t)h.qstart;
+    const uint32_t per = (nw + 63u) / 64u, w0 = lane * per, w1 = min(nw, w0 + per);
+    long long bs = INT64_MIN;
+    uint32_t bw = 0xFFFFFFFFu;
+    if (w0 < w1) {
+        long long sum = 0;
+        bool m;
+        for (uint32_t k = 0; k < Wn; k++) {
+            int32_t pt = (int32_t)(h.tstart + w0 + k);
+            sum += pair_score(T, Q, pt, pt - d, &m);
+        }
+        bs = sum; bw = w0;
+        for (uint32_t w = w0 + 1; w < w1; w++) {
+            int32_t add = (int32_t)(h.tstart + w + Wn - 1), sub = (int32_t)(h.tstart + w - 1);
+            sum += pair_score(T, Q, add, add - d, &m) - pair_score(T, Q, sub, sub - d, &m);
+            if (sum > bs) { bs = sum; bw = w; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        long long ob = __shfl_xor(bs, o);
+        uint32_t ow = __shfl_xor(bw, o);
+        if (ob > bs || (ob == bs && ow < bw)) { bs = ob; bw = ow; }
+    }
+    return bw + Wn / 2;
+}
+
+// anchors[b0 + r] = anchor point of the r-th chained HSP of the group (4 waves per group)
+__global__ __launch_bounds__(256) void k6_anchor_points(const Group *__restrict__ groups,
+                                                        const mimeo_hsp *__restrict__ hs,
+                                                        const uint32_t *__restrict__ order, uint2 *__restrict__ anchors) {
+    const Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    for (uint32_t r = threadIdx.x >> 6; r < G.nchain; r += 4) {
+        const mimeo_hsp h = hs[b0 + order[b0 + r]];
+        uint32_t off = wave_anchor_offset(G.T, G.Q, h);
+        if ((threadIdx.x & 63) == 0) anchors[b0 + r] = make_uint2(h.tstart + off, h.qstart + off);
+    }
+}
+
+__device__ __forceinline__ bool in_boxes(const mimeo_alignment *aln, uint32_t n, uint2 a) {
+    // wave-cooperative: is the anchor inside the box of any of the n earlier alignments?
+    bool inside = false;
+    for (uint32_t e = threadIdx.x & 63u; e < n; e += 64u) {
+        const mimeo_alignment &o = aln[e];
+        if (a.x >= o.tstart && a.x < o.tend && a.y >= o.qstart && a.y < o.qend) inside = true;
+    }
+    return __ballot(inside) != 0;
+}
+
+// one wave per group: choose the next <= bmax anchors that are outside every accepted box
+__global__ __launch_bounds__(64) void k6_pick(Group *__restrict__ groups, const uint2 *__restrict__ anchors,
+                                              const mimeo_alignment *__restrict__ aln, uint32_t bmax,
+                                              DpJob *__restrict__ jobs, unsigned int *__restrict__ njobs) {
+    Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    uint32_t next = G.next, nb = 0;
+    while (next < G.nchain && nb < bmax) {
+        uint2 a = anchors[b0 + next];
+        if (!in_boxes(aln + b0, G.nacc, a)) {
+            if (threadIdx.x == 0) G.batch[nb] = next;
+            nb++;
+        }
+        next++;
+    }
+    if (threadIdx.x == 0) {
+        G.next = next;
+        G.nbatch = nb;
+        unsigned int j0 = nb ? atomicAdd(njobs, 2u * nb) : 0u;
+        G.job0 = j0;
+        for (uint32_t k = 0; k < nb; k++) {
+            uint2 a = anchors[b0 + G.batch[k]];
+            jobs[j0 + 2 * k] = DpJob{blockIdx.x, a.x, a.y, -1};
+            jobs[j0 + 2 * k + 1] = DpJob{blockIdx.x, a.x, a.y, +1};
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
+                                            HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+    const DpJob job = jobs[blockIdx.x];
+    const Group &G = groups[job.group];
+    HalfResult r = wave_half_extend(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
+}
+
+// one wave per group: replay the skip rule over this round's batch, in anchor order
+__global__ __launch_bounds__(64) void k6_resolve(Group *__restrict__ groups, const uint2 *__restrict__ anchors,
+                                                 const HalfResult *__restrict__ res, mimeo_alignment *__restrict__ aln,
+                                                 unsigned int *__restrict__ remaining) {
+    __shared__ uint4 sbox[MAX_BATCH];  // boxes accepted in this round (tstart, tend, qstart, qend)
+    Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    const uint32_t nacc0 = G.nacc;
+    uint32_t nnew = 0, overflow = 0;
+    for (uint32_t k = 0; k < G.nbatch; k++) {
+        uint2 a = anchors[b0 + G.batch[k]];
+        bool inside = false;  // earlier rounds were already checked by k6_pick; look at this round's boxes
+        if (threadIdx.x < nnew) {
+            uint4 o = sbox[threadIdx.x];
+            inside = a.x >= o.x && a.x < o.y && a.y >= o.z && a.y < o.w;
+        }
+        if (__ballot(inside)) continue;
+        HalfResult L = res[G.job0 + 2 * k], R = res[G.job0 + 2 * k + 1];
+        overflow |= L.overflow | R.overflow;
+        if (threadIdx.x == 0) {
+            mimeo_alignment m;
+            m.tid = G.tid; m.qid = G.qid; m.qstrand = G.minus; m.reserved = 0;
+            m.tstart = a.x - L.i; m.tend = a.x + R.i; m.qstart = a.y - L.j; m.qend = a.y + R.j;
+            m.score = (int64_t)L.score + R.score;
+            m.id_n = L.nm + R.nm;
+            m.id_d = L.nm + R.nm + L.nx + R.nx;
+            aln[b0 + nacc0 + nnew] = m;
+            sbox[nnew] = make_uint4(m.tstart, m.tend, m.qstart, m.qend);
+        }
+        nnew++;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        G.nacc = nacc0 + nnew;
+        G.nbatch = 0;
+        if (overflow) G.overflow = 1;
+        if (G.next < G.nchain) atomicAdd(remaining, 1u);
+    }
+}
+
+// gap-free mode (--gapped off): every chained HSP is reported as is; identity by popcount
+__global__ __launch_bounds__(256) void k6_ungapped(Group *__restrict__ groups, const mimeo_hsp *__restrict__ hs,
+                                                   const uint32_t *__restrict__ order, mimeo_alignment *__restrict__ aln) {
+    Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t r = threadIdx.x >> 6; r < G.nchain; r += 4) {
+        const mimeo_hsp h = hs[b0 + order[b0 + r]];
+        const int32_t d = (int32_t)h.tstart - (int32_t)h.qstart;
+        uint32_t nmatch = 0;
+        for (uint32_t w0 = lane * 32u; w0 < h.length; w0 += 64u * 32u) {
+            int32_t pt = (int32_t)(h.tstart + w0), pq = pt - d;
+            uint32_t mm = ~((get32(G.T.lo, pt) ^ get32(G.Q.lo, pq)) | (get32(G.T.hi, pt) ^ get32(G.Q.hi, pq))) &
+                          ~(get32(G.T.nm, pt) | get32(G.Q.nm, pq));
+            uint32_t rem = h.length - w0;
+            if (rem < 32) mm &= (1u << rem) - 1u;
+            nmatch += __popc(mm);
+        }
+        for (int o = 32; o > 0; o >>= 1) nmatch += __shfl_xor(nmatch, o);
+        if (lane == 0) {
+            mimeo_alignment m;
+            m.tid = G.tid; m.qid = G.qid; m.qstrand = G.minus; m.reserved = 0;
+            m.tstart = h.tstart; m.tend = h.tstart + h.length; m.qstart = h.qstart; m.qend = h.qstart + h.length;
+            m.score = h.score; m.id_n = nmatch; m.id_d = h.length;
+            aln[b0 + r] = m;
+        }
+    }
+    if (threadIdx.x == 0) G.nacc = G.nchain;
+}
+
+// threshold, minus-strand coordinates -> query plus strand (start2+/end2+), compaction
+__global__ void k6_finish(Group *__restrict__ groups, uint32_t ngroups, mimeo_alignment *__restrict__ aln,
+                          int32_t thresh) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    Group &G = groups[g];
+    const uint64_t b0 = G.hsp_begin;
+    uint32_t k = 0;
+    for (uint32_t e = 0; e < G.nacc; e++) {
+        mimeo_alignment a = aln[b0 + e];
+        if (a.score < thresh) continue;
+        if (G.minus) { uint32_t s = G.Q.len - a.qend, t2 = G.Q.len - a.qstart; a.qstart = s; a.qend = t2; }
+        aln[b0 + k++] = a;
+    }
+    G.naln = k;
+}
+
+static DeviceBuf g_anchors, g_jobs, g_res, g_cnt;
+
+int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
+                  uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln) {
+    if (!ngroups || !nhsps) return 0;
+    hipStream_t st = stream();
+    int rc;
+    if (!p->gapped) {
+        hipLaunchKernelGGL(k6_ungapped, dim3(ngroups), dim3(256), 0, st, d_groups, d_sorted, d_order, d_aln);
+    } else {
+        uint32_t bmax = 4096u / ngroups;
+        bmax = bmax < 1 ? 1 : (bmax > MAX_BATCH ? MAX_BATCH : bmax);
+        if ((rc = g_anchors.reserve(nhsps * sizeof(uint2)))) return rc;
+        if ((rc = g_jobs.reserve((size_t)ngroups * bmax * 2 * sizeof(DpJob)))) return rc;
+        if ((rc = g_res.reserve((size_t)ngroups * bmax * 2 * sizeof(HalfResult)))) return rc;
+        if ((rc = g_cnt.reserve(16))) return rc;
+        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups), dim3(256), 0, st, (const Group *)d_groups, d_sorted, d_order,
+                           (uint2 *)g_anchors.p);
+        for (;;) {
+            HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 8, st));
+            unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1;
+            hipLaunchKernelGGL(k6_pick, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
+                               (const mimeo_alignment *)d_aln, bmax, (DpJob *)g_jobs.p, njobs);
+            unsigned int h[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h[0])
+                hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
+                                   (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+            hipLaunchKernelGGL(k6_resolve, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
+                               (const HalfResult *)g_res.p, d_aln, remaining);
+            HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (!h[1]) break;
+        }
+    }
+    hipLaunchKernelGGL(k6_finish, dim3((ngroups + 63) / 64), dim3(64), 0, st, d_groups, ngroups, d_aln, p->hspthresh);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mimeo

@@ -135,7 +135,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             for (size_t gi = 0; gi < groups.size(); gi++) {
                 const Group &g = groups[gi];
                 if (g.overflow) {
-                    set_error("gapped extension band wider than the LDS ring (RING columns): not supported yet");
+                    set_error("gapped extension: DP band wider than the 512-column register window, or score beyond int32: not supported yet");
                     rc = MIMEO_ERR_LIMIT;
                     break;
                 }
@@ -164,6 +164,39 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     g_stats.ms_chain = ms_chain;
     g_stats.ms_gapped = ms_gapped;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps,
+                        const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,
+                        float *ms_gapped) {
+    if (!ngroups || !nhsps) return 0;
+    hipStream_t st = stream();
+    // scratch: sorted HSPs | best | cand | pred | order
+    size_t off_hs = 0, off_best = off_hs + nhsps * sizeof(mimeo_hsp), off_cand = off_best + nhsps * 8,
+           off_pred = off_cand + nhsps * 8, off_order = off_pred + nhsps * 4, total = off_order + nhsps * 4;
+    int rc = scratch.reserve(total);
+    if (rc) return rc;
+    char *b = (char *)scratch.p;
+    hipEvent_t e0, e1, e2;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    HIP_TRY(hipEventRecord(e0, st));
+    if ((rc = chain_device(d_groups, ngroups, d_hsps, nhsps, p->chain, (mimeo_hsp *)(b + off_hs), (long long *)(b + off_best),
+                           (long long *)(b + off_cand), (int *)(b + off_pred), (uint32_t *)(b + off_order))))
+        return rc;
+    HIP_TRY(hipEventRecord(e1, st));
+    if ((rc = gapped_device(d_groups, ngroups, (const mimeo_hsp *)(b + off_hs), (const uint32_t *)(b + off_order), nhsps, p,
+                            d_aln)))
+        return rc;
+    HIP_TRY(hipEventRecord(e2, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    float a = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&c, e1, e2));
+    if (ms_chain) *ms_chain += a;
+    if (ms_gapped) *ms_gapped += c;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return 0;
 }
 
