@@ -213,12 +213,93 @@ __device__ WalkResult wave_walk(const StrandView &T, const StrandView &Q, int32_
     return r;
 }
 
+// Word-granular walk without seed detection: 64 lanes x 32 bases per step.  Each lane reduces
+// its 32-base word to (sum S, best prefix M and its position, lowest prefix mn, deepest drop below
+// the running in-word maximum a); a wave prefix sum / prefix max turns these into the exact
+// running score and best at every word boundary, and the walk can only stop inside the first word
+// with  a < -xdrop  or  run_in + mn < best_in - xdrop, which that lane then replays base by base.
+// Words that are all matches (the common case on long diagonals) need no per-base loop at all.
+__device__ WalkResult wave_walk_fast(const StrandView &T, const StrandView &Q, int32_t et, int32_t d, int dir,
+                                     uint32_t maxsteps, int xdrop) {
+    const uint32_t lane = threadIdx.x & 63u;
+    WalkResult r{0, 0, false, 0};
+    int64_t run = 0;
+    for (uint32_t base = 0; base < maxsteps; base += 2048u) {
+        const uint32_t off = base + lane * 32u;
+        const uint32_t nst = off < maxsteps ? min(32u, maxsteps - off) : 0u;
+        uint32_t dl = 0, dh = 0, cg = 0, nn = 0;
+        if (nst) {
+            // bit b of every mask <-> step off + b
+            int32_t pt = dir > 0 ? et + (int32_t)off : et - (int32_t)off - 32, pq = pt - d;
+            uint32_t tlo = get32(T.lo, pt), thi = get32(T.hi, pt);
+            dl = tlo ^ get32(Q.lo, pq); dh = thi ^ get32(Q.hi, pq); cg = tlo ^ thi;
+            nn = get32(T.nm, pt) | get32(Q.nm, pq);
+            if (dir < 0) { dl = __brev(dl); dh = __brev(dh); cg = __brev(cg); nn = __brev(nn); }
+        }
+        const uint32_t valid = nst == 32 ? 0xFFFFFFFFu : ((1u << nst) - 1u);
+        int32_t S = 0, M = INT32_MIN / 2, mn = INT32_MAX / 2, a = 0;
+        uint32_t posM = 0;
+        if (nst) {
+            if (((dl | dh | nn) & valid) == 0) {  // all matches: prefixes strictly increase
+                S = 91 * (int32_t)nst + 9 * __popc(cg & valid);
+                M = S; posM = nst; mn = (cg & 1u) ? 100 : 91; a = 0;
+            } else {
+                int32_t p = 0;
+                for (uint32_t b = 0; b < nst; b++) {
+                    p += sub_score((dl >> b) & 1u, (dh >> b) & 1u, (cg >> b) & 1u, (nn >> b) & 1u);
+                    if (p > M) { M = p; posM = b + 1; }
+                    mn = min(mn, p);
+                    a = min(a, p - M);
+                }
+                S = p;
+            }
+        }
+        // running score entering my word, best entering my word
+        int64_t incS = wave_incl_sum((int64_t)S, lane);
+        int64_t run_in = run + incS - S;
+        int64_t cand = nst ? run_in + M : INT64_MIN;  // best reached inside my word
+        int64_t incB = wave_incl_max(cand, lane);
+        int64_t prevB = __shfl_up(incB, 1);
+        int64_t best_in = lane ? max(r.best, prevB) : r.best;
+        bool mb = nst && (a < -xdrop || run_in + mn < best_in - xdrop);
+        uint64_t bmask = __ballot(mb);
+        uint32_t first = bmask ? (uint32_t)__builtin_ctzll(bmask) : 64u;
+        // accept every word before `first`: best = earliest word reaching the maximum
+        int64_t cm = wave_max((lane < first && nst) ? cand : INT64_MIN);
+        if (cm > r.best) {
+            uint64_t em = __ballot(lane < first && nst && cand == cm);
+            uint32_t wl = (uint32_t)__builtin_ctzll(em);
+            r.best = cm;
+            r.bsteps = base + wl * 32u + (uint32_t)__shfl((int)posM, (int)wl);
+        }
+        if (first < 64u) {
+            // the walk ends inside word `first`: replay it exactly on that lane
+            int64_t lb = r.best;
+            uint32_t lbs = r.bsteps;
+            if (lane == first) {
+                int64_t p = run_in;
+                for (uint32_t b = 0; b < nst; b++) {
+                    p += sub_score((dl >> b) & 1u, (dh >> b) & 1u, (cg >> b) & 1u, (nn >> b) & 1u);
+                    if (p > lb) { lb = p; lbs = off + b + 1; }
+                    if (p < lb - xdrop) break;
+                }
+            }
+            r.best = __shfl(lb, (int)first);
+            r.bsteps = (uint32_t)__shfl((int)lbs, (int)first);
+            return r;
+        }
+        run += __shfl(incS, 63);
+    }
+    return r;
+}
+
 // full extension of one hit by one wavefront; emits candidate or follower record (lane 0)
 __device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2 h, int xdrop, int hspthresh,
                                  int transitions, bool detect, ExtCounters *ctr, Cand *cand, uint64_t cand_cap,
                                  uint64_t *fkey, uint32_t *fprev, uint32_t *rext_out) {
     const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN, d = (int32_t)h.x - (int32_t)h.y;
-    WalkResult L = wave_walk(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop, detect, transitions);
+    WalkResult L = detect ? wave_walk(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop, true, transitions)
+                          : wave_walk_fast(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop);
     if (L.found) {
         if ((threadIdx.x & 63) == 0) {
             unsigned long long i = atomicAdd(&ctr->nfollow, 1ull);
@@ -227,8 +308,7 @@ __device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2
         }
         return;
     }
-    WalkResult R = wave_walk(T, Q, et, d, +1, min(T.len - (uint32_t)et, Q.len - (uint32_t)eq), xdrop, false,
-                             transitions);
+    WalkResult R = wave_walk_fast(T, Q, et, d, +1, min(T.len - (uint32_t)et, Q.len - (uint32_t)eq), xdrop);
     if (rext_out) *rext_out = R.bsteps;
     int64_t score = L.best + R.best;
     if (score >= hspthresh && (threadIdx.x & 63) == 0) {
@@ -280,19 +360,17 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T,
     const int32_t d = (int32_t)(uint32_t)(k0 >> 32) - (int32_t)Q.len;
     // head: seed end = prev[beg]; only its right extent matters (it was emitted by K4a/K4b)
     int32_t het = (int32_t)prev[beg];
-    WalkResult R = wave_walk(T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop, false,
-                             transitions);
+    WalkResult R = wave_walk_fast(T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop);
     uint32_t reach = (uint32_t)het + R.bsteps;
     uint64_t i = beg;
     while (i < end) {
-        // first member at or after i whose seed end lies beyond reach
-        uint64_t nxt = end;
-        for (uint64_t j = i; j < end; j += 64) {
-            uint64_t jj = j + lane;
-            bool ok = jj < end && (uint32_t)key[jj] > reach;
-            uint64_t m = __ballot(ok);
-            if (m) { nxt = j + (uint64_t)__builtin_ctzll(m); break; }
+        // first member at or after i whose seed end lies beyond reach (members are sorted by seed end)
+        uint64_t lo = i, hi = end;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint32_t)key[mid] > reach) hi = mid; else lo = mid + 1;
         }
+        uint64_t nxt = lo;
         if (nxt >= end) break;
         uint32_t et = (uint32_t)key[nxt];
         uint2 h = make_uint2(et - SEED_LEN, (uint32_t)((int32_t)et - d) - SEED_LEN);

@@ -216,47 +216,70 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
     return best;
 }
 
-// best 31-column window of an HSP (wave-cooperative): offset of its centre
-__device__ uint32_t wave_anchor_offset(const StrandView &T, const StrandView &Q, const mimeo_hsp &h) {
-    const uint32_t Wn = 31;
-    if (h.length <= Wn) return h.length / 2;
-    const uint32_t lane = threadIdx.x & 63u, nw = h.length - Wn + 1;
+// Anchor = centre of the best 31-column window of the HSP (first maximum).  Windows are cut into
+// chunks of ANCHOR_CHUNK starts; a wave scans one chunk (each lane slides over 64 consecutive
+// starts) and folds its best (sum, start) into a packed 64-bit word with atomicMax — high half
+// = biased sum, low half = ~start, so the maximum is the highest sum at the smallest start.
+constexpr uint32_t ANCHOR_W = 31, ANCHOR_CHUNK = 4096;
+constexpr int ANCHOR_THREADS = 1024;
+
+__device__ void wave_anchor_chunk(const StrandView &T, const StrandView &Q, const mimeo_hsp &h, uint32_t chunk,
+                                  unsigned long long *packed) {
+    const uint32_t lane = threadIdx.x & 63u, nw = h.length - ANCHOR_W + 1;
     const int32_t d = (int32_t)h.tstart - (int32_t)h.qstart;
-    const uint32_t per = (nw + 63u) / 64u, w0 = lane * per, w1 = min(nw, w0 + per);
-    long long bs = INT64_MIN;
+    const uint32_t w0 = chunk * ANCHOR_CHUNK + lane * (ANCHOR_CHUNK / 64u), w1 = min(nw, w0 + ANCHOR_CHUNK / 64u);
+    int32_t bs = INT32_MIN;
     uint32_t bw = 0xFFFFFFFFu;
     if (w0 < w1) {
-        long long sum = 0;
+        int32_t sum = 0;
         bool m;
-        for (uint32_t k = 0; k < Wn; k++) {
+        for (uint32_t k = 0; k < ANCHOR_W; k++) {
             int32_t pt = (int32_t)(h.tstart + w0 + k);
             sum += pair_score(T, Q, pt, pt - d, &m);
         }
         bs = sum; bw = w0;
         for (uint32_t w = w0 + 1; w < w1; w++) {
-            int32_t add = (int32_t)(h.tstart + w + Wn - 1), sub = (int32_t)(h.tstart + w - 1);
+            int32_t add = (int32_t)(h.tstart + w + ANCHOR_W - 1), sub = (int32_t)(h.tstart + w - 1);
             sum += pair_score(T, Q, add, add - d, &m) - pair_score(T, Q, sub, sub - d, &m);
             if (sum > bs) { bs = sum; bw = w; }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
-        long long ob = __shfl_xor(bs, o);
+        int32_t ob = __shfl_xor(bs, o);
         uint32_t ow = __shfl_xor(bw, o);
         if (ob > bs || (ob == bs && ow < bw)) { bs = ob; bw = ow; }
     }
-    return bw + Wn / 2;
+    if (lane == 0 && bw != 0xFFFFFFFFu)
+        atomicMax(packed, ((unsigned long long)(uint32_t)(bs + 8192) << 32) | (unsigned long long)(0xFFFFFFFFu - bw));
 }
 
-// anchors[b0 + r] = anchor point of the r-th chained HSP of the group (4 waves per group)
-__global__ __launch_bounds__(256) void k6_anchor_points(const Group *__restrict__ groups,
-                                                        const mimeo_hsp *__restrict__ hs,
-                                                        const uint32_t *__restrict__ order, uint2 *__restrict__ anchors) {
+// anchors[b0 + r] = anchor point of the r-th chained HSP of the group (16 waves per group share
+// the (HSP, chunk) items round-robin)
+__global__ __launch_bounds__(ANCHOR_THREADS) void k6_anchor_points(const Group *__restrict__ groups,
+                                                                   const mimeo_hsp *__restrict__ hs,
+                                                                   const uint32_t *__restrict__ order,
+                                                                   unsigned long long *__restrict__ packed,
+                                                                   uint2 *__restrict__ anchors) {
     const Group &G = groups[blockIdx.x];
     const uint64_t b0 = G.hsp_begin;
-    for (uint32_t r = threadIdx.x >> 6; r < G.nchain; r += 4) {
+    const uint32_t wave = threadIdx.x >> 6, nwaves = ANCHOR_THREADS / 64;
+    uint32_t item = 0;
+    for (uint32_t r = 0; r < G.nchain; r++) {
         const mimeo_hsp h = hs[b0 + order[b0 + r]];
-        uint32_t off = wave_anchor_offset(G.T, G.Q, h);
-        if ((threadIdx.x & 63) == 0) anchors[b0 + r] = make_uint2(h.tstart + off, h.qstart + off);
+        if (h.length <= ANCHOR_W) continue;
+        const uint32_t nch = (h.length - ANCHOR_W + 1 + ANCHOR_CHUNK - 1) / ANCHOR_CHUNK;
+        for (uint32_t c = 0; c < nch; c++, item++)
+            if (item % nwaves == wave) wave_anchor_chunk(G.T, G.Q, h, c, &packed[b0 + r]);
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < G.nchain; r += ANCHOR_THREADS) {
+        const mimeo_hsp h = hs[b0 + order[b0 + r]];
+        uint32_t off = h.length / 2;
+        if (h.length > ANCHOR_W) {
+            unsigned long long v = __hip_atomic_load(&packed[b0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            off = (0xFFFFFFFFu - (uint32_t)v) + ANCHOR_W / 2;
+        }
+        anchors[b0 + r] = make_uint2(h.tstart + off, h.qstart + off);
     }
 }
 
@@ -393,7 +416,7 @@ __global__ void k6_finish(Group *__restrict__ groups, uint32_t ngroups, mimeo_al
     G.naln = k;
 }
 
-static DeviceBuf g_anchors, g_jobs, g_res, g_cnt;
+static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt;
 
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln) {
@@ -406,11 +429,13 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         uint32_t bmax = 4096u / ngroups;
         bmax = bmax < 1 ? 1 : (bmax > MAX_BATCH ? MAX_BATCH : bmax);
         if ((rc = g_anchors.reserve(nhsps * sizeof(uint2)))) return rc;
+        if ((rc = g_packed.reserve(nhsps * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(g_packed.p, 0, nhsps * 8, st));
         if ((rc = g_jobs.reserve((size_t)ngroups * bmax * 2 * sizeof(DpJob)))) return rc;
         if ((rc = g_res.reserve((size_t)ngroups * bmax * 2 * sizeof(HalfResult)))) return rc;
         if ((rc = g_cnt.reserve(16))) return rc;
-        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups), dim3(256), 0, st, (const Group *)d_groups, d_sorted, d_order,
-                           (uint2 *)g_anchors.p);
+        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups, d_sorted,
+                           d_order, (unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);
         for (;;) {
             HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 8, st));
             unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1;
