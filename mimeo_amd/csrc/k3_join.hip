@@ -9,16 +9,15 @@
 // loads and resolves every probe from LDS.  HBM traffic per (target, query-strand) unit is the
 // two offset arrays + the position lists once + the hit records.
 //
-// Two launches: k3_join_count (per-tile hit counts) -> k3_tile_scan -> k3_join_fill.  The fill
-// kernel places hits with a workgroup prefix sum, stages each 256-word chunk in LDS and writes
-// it out with coalesced 8-byte-per-lane stores, so the output order is deterministic:
+// Launches: k3_join_count (per-tile hit counts) -> k3_tile_scan -> k3_join_fill.  The fill kernel
+// places hits with a workgroup prefix sum, stages them in LDS and writes them out with coalesced
+// 8-byte-per-lane stores, so the output order is deterministic:
 // (key, target position, neighbour, query position).
 #include "common.h"
 
 namespace mimeo {
 
 constexpr int JOIN_THREADS = 256;
-constexpr int JOIN_STAGE = 3072;  // hits staged in LDS per 256-word chunk (24 KiB)
 
 __device__ __forceinline__ void load_tile_offsets(const uint32_t *__restrict__ off, uint32_t tile,
                                                   uint32_t *s) {
@@ -88,7 +87,23 @@ __global__ __launch_bounds__(1024) void k3_tile_scan(const unsigned long long *_
     if (threadIdx.x == 1023) base[NTILE] = part[1023];
 }
 
-__global__ __launch_bounds__(JOIN_THREADS) void k3_join_fill(const uint32_t *__restrict__ offT,
+// Fill: one thread per TARGET ENTRY of the tile (not per key): entry g of the CSR position list
+// finds its key by a binary search over the LDS-resident offsets, counts the query entries of its
+// 13 neighbour keys, a workgroup prefix sum places its hits in an LDS stage, and the stage is
+// written out with coalesced 8-byte-per-lane stores.  Entries are taken in passes sized so that a
+// pass's hits normally fit the stage; a pass that does not fit writes straight to global memory.
+constexpr int FILL_THREADS = 512;
+constexpr int FILL_STAGE = 4096;  // hits (32 KiB)
+
+__device__ __forceinline__ void load_tile_offsets_n(const uint32_t *__restrict__ off, uint32_t tile, uint32_t *s,
+                                                    int nthreads) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(off + (size_t)tile * TILE_WORDS);
+    uint4 *dst = reinterpret_cast<uint4 *>(s);
+    for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += nthreads) dst[k] = src[k];
+    if (threadIdx.x == 0) s[TILE_WORDS] = off[(size_t)tile * TILE_WORDS + TILE_WORDS];
+}
+
+__global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__restrict__ offT,
                                                              const uint32_t *__restrict__ posT,
                                                              const uint32_t *__restrict__ offQ,
                                                              const uint32_t *__restrict__ posQ, int transitions,
@@ -96,20 +111,38 @@ __global__ __launch_bounds__(JOIN_THREADS) void k3_join_fill(const uint32_t *__r
                                                              uint2 *__restrict__ hits) {
     __shared__ __attribute__((aligned(16))) uint32_t sT[TILE_WORDS + 4];
     __shared__ __attribute__((aligned(16))) uint32_t sQ[TILE_WORDS + 4];
-    __shared__ uint2 stage[JOIN_STAGE];
-    __shared__ uint32_t wsum[JOIN_THREADS / 64];
-    uint32_t tile = blockIdx.x;
+    __shared__ uint2 stage[FILL_STAGE];
+    __shared__ uint32_t wsum[FILL_THREADS / 64];
+    const uint32_t tile = blockIdx.x;
     unsigned long long out = tile_base[tile];
-    if (tile_base[tile + 1] == out) return;  // empty tile
-    load_tile_offsets(offT, tile, sT);
-    load_tile_offsets(offQ, tile, sQ);
+    const unsigned long long tile_hits = tile_base[tile + 1] - out;
+    if (tile_hits == 0) return;  // empty tile
+    load_tile_offsets_n(offT, tile, sT, FILL_THREADS);
+    load_tile_offsets_n(offQ, tile, sQ, FILL_THREADS);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t k = 0; k < TILE_WORDS / JOIN_THREADS; k++) {
-        uint32_t w = k * JOIN_THREADS + threadIdx.x;
-        uint32_t t0 = sT[w], nT = sT[w + 1] - t0;
-        uint32_t c = nT ? nT * neighbour_sum(sQ, w, transitions) : 0;
-        // workgroup exclusive scan of c
+    const uint32_t t0 = sT[0], nT = sT[TILE_WORDS] - t0;
+    // entries per pass: aim at <= FILL_STAGE hits per pass from the tile's mean hits per entry
+    uint32_t P = FILL_THREADS;
+    if (tile_hits > FILL_STAGE && nT) {
+        unsigned long long per = (unsigned long long)FILL_STAGE * nT / tile_hits;
+        P = per < 64 ? 64u : (per > FILL_THREADS ? FILL_THREADS : (uint32_t)per & ~63u);
+        if (P < 64) P = 64;
+    }
+    for (uint32_t e0 = 0; e0 < nT; e0 += P) {
+        const uint32_t e = e0 + threadIdx.x;
+        const bool active = threadIdx.x < P && e < nT;
+        uint32_t w = 0, c = 0;
+        const uint32_t g = t0 + e;
+        if (active) {
+            uint32_t lo = 0, hi = TILE_WORDS;  // largest w with sT[w] <= g
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (sT[mid] <= g) lo = mid; else hi = mid;
+            }
+            w = lo;
+            c = neighbour_sum(sQ, w, transitions);
+        }
         uint32_t inc = c;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t v = __shfl_up(inc, o);
@@ -119,27 +152,25 @@ __global__ __launch_bounds__(JOIN_THREADS) void k3_join_fill(const uint32_t *__r
         __syncthreads();
         uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (int i = 0; i < JOIN_THREADS / 64; i++) {
+        for (int i = 0; i < FILL_THREADS / 64; i++) {
             uint32_t v = wsum[i];
             if ((uint32_t)i < wave) wbase += v;
             total += v;
         }
-        uint32_t o = wbase + inc - c;
-        bool staged = total <= JOIN_STAGE;
+        const uint32_t o = wbase + inc - c;
+        const bool staged = total <= FILL_STAGE;
         if (c) {
+            const uint32_t tp = posT[g];
             uint2 *dst = staged ? stage + o : hits + out + o;
-            for (uint32_t a = 0; a < nT; a++) {
-                uint32_t tp = posT[t0 + a];
-                for (int j = -1; j < (transitions ? SEED_WEIGHT : 0); j++) {
-                    uint32_t w2 = j < 0 ? w : (w ^ (1u << j));
-                    uint32_t q0 = sQ[w2], q1 = sQ[w2 + 1];
-                    for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, posQ[b]);
-                }
+            for (int j = -1; j < (transitions ? SEED_WEIGHT : 0); j++) {
+                const uint32_t w2 = j < 0 ? w : (w ^ (1u << j));
+                const uint32_t q0 = sQ[w2], q1 = sQ[w2 + 1];
+                for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, posQ[b]);
             }
         }
         __syncthreads();
         if (staged) {
-            for (uint32_t i = threadIdx.x; i < total; i += JOIN_THREADS) hits[out + i] = stage[i];
+            for (uint32_t i = threadIdx.x; i < total; i += FILL_THREADS) hits[out + i] = stage[i];
             __syncthreads();
         }
         out += total;
@@ -189,7 +220,7 @@ int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g_ev[2], st));
     if (total)
-        hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, T.pos, Q.off, Q.pos, transitions,
+        hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(FILL_THREADS), 0, st, T.off, T.pos, Q.off, Q.pos, transitions,
                            g_tile_base, (uint2 *)hits.p);
     HIP_TRY(hipEventRecord(g_ev[3], st));
     HIP_TRY(hipGetLastError());

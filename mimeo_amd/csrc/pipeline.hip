@@ -3,9 +3,9 @@
 //
 // Pairs are grouped by target scaffold.  A scaffold strand's seed index is built once and
 // kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  For
-// each target: every (query, strand) unit runs K3 (index join) and K4 (gap-free extension); the
-// HSPs of all units of the target are then chained and gap-extended in one launch pair (K5/K6,
-// one workgroup per unit).
+// every (target, query, strand) unit K3 (index join) and K4 (gap-free extension) run one unit at a
+// time; the HSPs of up to MAX_GROUPS units are then chained and gap-extended together (K5/K6, one
+// workgroup per unit in K5, one wavefront per half extension in K6).
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -73,6 +73,39 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     hipStream_t st = stream();
     int rc = 0;
     uint64_t pos = 0;
+    // units (target, query, strand) accumulate into one batch of groups; K5/K6 run once per batch
+    std::vector<Group> groups;
+    std::vector<uint64_t> group_pair;
+    uint64_t nh_total = 0;
+    const size_t MAX_GROUPS = 8192;
+    auto flush = [&]() -> int {
+        int frc = 0;
+        if (nh_total && !groups.empty()) {
+            if ((frc = g_groups.reserve(groups.size() * sizeof(Group)))) return frc;
+            if ((frc = g_aln.reserve(nh_total * sizeof(mimeo_alignment)))) return frc;
+            HIP_TRY(hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st));
+            if ((frc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_all_hsps.p,
+                                           nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain, &ms_gapped)))
+                return frc;
+            HIP_TRY(hipMemcpy(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost));
+            std::vector<mimeo_alignment> host_aln(nh_total);
+            HIP_TRY(hipMemcpy(host_aln.data(), g_aln.p, nh_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost));
+            for (size_t gi = 0; gi < groups.size(); gi++) {
+                const Group &g = groups[gi];
+                if (g.overflow) {
+                    set_error("gapped extension: DP band wider than the 1024-column register window, or score beyond int32: not supported yet");
+                    return MIMEO_ERR_LIMIT;
+                }
+                g_stats.chained_hsps += g.nchain;
+                auto &dst = per_pair[group_pair[gi]];
+                dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
+            }
+        }
+        groups.clear();
+        group_pair.clear();
+        nh_total = 0;
+        return 0;
+    };
     while (pos < npairs && !rc) {
         uint32_t tid = pair_t[ord[pos]];
         uint64_t end = pos;
@@ -81,9 +114,6 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         IndexView ti;
         StrandView tv;
         if ((rc = cache.get(ts, 0, true, &ti, &tv))) break;
-        std::vector<Group> groups;
-        std::vector<uint64_t> group_pair;
-        uint64_t nh_total = 0;
         for (uint64_t k = pos; k < end && !rc; k++) {
             uint32_t qid = pair_q[ord[k]];
             const Scaffold &qs = QG->scaf[qid];
@@ -95,7 +125,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                 uint64_t nhits = 0, nh = 0;
                 if ((rc = join_hits(ti, qi, p->transitions, g_hits, &nhits, &tm))) break;
                 if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)g_hits.p, nhits, p, g_unit_hsps, &nh, &ms_ext))) break;
-                // append this unit's HSPs to the target-level array
+                // append this unit's HSPs to the batch-level array
                 if ((nh_total + nh) * sizeof(mimeo_hsp) > g_all_hsps.cap) {
                     DeviceBuf bigger;
                     if ((rc = bigger.reserve((nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) break;
@@ -119,33 +149,12 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                 g_stats.scan_bytes_algorithmic += scan_bytes_algorithmic(qs.len, nhits);
                 g_stats.scan_bytes_kernel += scan_bytes_kernel(ti.n, qi.n, nhits);
                 g_stats.scan_launches++;
-            }
-        }
-        if (rc) break;
-        if (nh_total && !groups.empty()) {
-            if ((rc = g_groups.reserve(groups.size() * sizeof(Group)))) break;
-            if ((rc = g_aln.reserve(nh_total * sizeof(mimeo_alignment)))) break;
-            HIP_TRY(hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st));
-            if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_all_hsps.p,
-                                          nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain, &ms_gapped)))
-                break;
-            HIP_TRY(hipMemcpy(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost));
-            std::vector<mimeo_alignment> host_aln(nh_total);
-            HIP_TRY(hipMemcpy(host_aln.data(), g_aln.p, nh_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost));
-            for (size_t gi = 0; gi < groups.size(); gi++) {
-                const Group &g = groups[gi];
-                if (g.overflow) {
-                    set_error("gapped extension: DP band wider than the 512-column register window, or score beyond int32: not supported yet");
-                    rc = MIMEO_ERR_LIMIT;
-                    break;
-                }
-                g_stats.chained_hsps += g.nchain;
-                auto &dst = per_pair[group_pair[gi]];
-                dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
+                if (groups.size() >= MAX_GROUPS) rc = flush();
             }
         }
         pos = end;
     }
+    if (!rc) rc = flush();
     cache.clear();
     if (rc) return rc;
     uint64_t total = 0;
