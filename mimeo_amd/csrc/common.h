@@ -1,15 +1,18 @@
 // common.h — shared declarations of the mimeo HIP engine (gfx950 only).
 //
 // Data layout in HBM:
-//   a scaffold strand is stored as 1-bit planes, one u32 word per 32 bases, base i at bit
-//   (i & 31) of word (i >> 5):
-//     lo  — bit 0 of the 2-bit code (A0 C1 G2 T3)
-//     hi  — bit 1 of the 2-bit code; a transition (A<->G, C<->T) flips exactly this bit
-//     nm  — 1 where the base is not ACGT (scored as N)
-//     sv  — 1 where a valid 12of19 seed word starts (no N, and for the target no lower case,
-//           inside the 19-base window, and the window fits)
-//   Every plane has PLANE_PAD zero words in front of word 0 and behind the last word so that
-//   window loads never need a bounds check.
+//   a scaffold strand is stored as four 1-bit planes, interleaved word by word: pw[w] is a uint4
+//   holding 32 bases (base i at bit (i & 31) of word (i >> 5)) of
+//     .x lo — bit 0 of the 2-bit code (A0 C1 G2 T3)
+//     .y hi — bit 1 of the 2-bit code; a transition (A<->G, C<->T) flips exactly this bit
+//     .z nm — 1 where the base is not ACGT (scored as N)
+//     .w sv — 1 where a valid 12of19 seed word starts in the QUERY role (no N inside the 19-base
+//             window, and the window fits)
+//   so one 64-byte cache line carries all planes of 128 consecutive bases: an extension touches
+//   one or two lines per sequence instead of one per plane.  A scaffold with lower-case bases has
+//   an extra plane svt = seed validity in the TARGET role (lastz excludes soft-masked target
+//   bases from seeding).  PLANE_PAD zero words lie in front of word 0 and behind the last word
+//   so that window loads never need a bounds check.
 //   The seed index of a strand is CSR: off[2^24 + 1] (u32) and pos[nvalid] (u32, ascending
 //   inside a bucket).  Key = (pext12(lo window) << 12) | pext12(hi window): the low 12 bits are
 //   the transition bits, so the 13 words within one transition of a key differ only in the low
@@ -42,8 +45,9 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 // device views ---------------------------------------------------------------------------
 struct StrandView {
-    const uint32_t *lo, *hi, *nm, *sv;  // pointers to word 0 (padding lies before/after)
-    uint32_t len;                        // bases
+    const uint4 *pw;       // interleaved planes {lo, hi, nm, sv}, pointer to word 0
+    const uint32_t *svt;   // target-role seed validity plane (word 0), or null: use pw[].w
+    uint32_t len;          // bases
 };
 
 struct IndexView {
@@ -54,7 +58,7 @@ struct IndexView {
 
 // host-side owner of one strand's planes
 struct Strand {
-    uint32_t *base = nullptr;  // one allocation: lo | hi | nm | sv (each nwords + 2*PLANE_PAD)
+    uint4 *base = nullptr;          // nwords + 2*PLANE_PAD interleaved words
     uint32_t *sv_target = nullptr;  // separate sv plane for the target role (soft-mask aware); null = same as sv
     uint32_t nwords = 0;
     uint32_t len = 0;

@@ -4,22 +4,52 @@
 
 namespace mimeo {
 
-// 32 / 64 consecutive plane bits starting at (possibly negative, padded) base index s
+struct Win32 { uint32_t lo, hi, nm, sv; };
+struct Win64 { uint64_t lo, hi, nm, sv; };
+
+// 32 consecutive bases of every plane starting at (possibly negative, padded) base index s:
+// two 16-byte loads, normally from the same cache line
+__device__ __forceinline__ Win32 win32(const StrandView &v, int32_t s) {
+    const int32_t w = s >> 5;
+    const uint32_t b = (uint32_t)s & 31u;
+    const uint4 a = v.pw[w], c = v.pw[w + 1];
+    Win32 r;
+    r.lo = (uint32_t)((((uint64_t)c.x << 32) | a.x) >> b);
+    r.hi = (uint32_t)((((uint64_t)c.y << 32) | a.y) >> b);
+    r.nm = (uint32_t)((((uint64_t)c.z << 32) | a.z) >> b);
+    r.sv = (uint32_t)((((uint64_t)c.w << 32) | a.w) >> b);
+    return r;
+}
+// 64 consecutive bases of every plane
+__device__ __forceinline__ Win64 win64(const StrandView &v, int32_t s) {
+    const int32_t w = s >> 5;
+    const uint32_t b = (uint32_t)s & 31u;
+    const uint4 a = v.pw[w], c = v.pw[w + 1], e = v.pw[w + 2];
+    Win64 r;
+    uint64_t l;
+    l = ((uint64_t)c.x << 32) | a.x; r.lo = b ? (l >> b) | ((uint64_t)e.x << (64 - b)) : l;
+    l = ((uint64_t)c.y << 32) | a.y; r.hi = b ? (l >> b) | ((uint64_t)e.y << (64 - b)) : l;
+    l = ((uint64_t)c.z << 32) | a.z; r.nm = b ? (l >> b) | ((uint64_t)e.z << (64 - b)) : l;
+    l = ((uint64_t)c.w << 32) | a.w; r.sv = b ? (l >> b) | ((uint64_t)e.w << (64 - b)) : l;
+    return r;
+}
+// 32 bits of a plain (non-interleaved) plane
 __device__ __forceinline__ uint32_t get32(const uint32_t *__restrict__ pl, int32_t s) {
     int32_t w = s >> 5;
     uint32_t b = (uint32_t)s & 31u;
     uint64_t v = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
     return (uint32_t)(v >> b);
 }
-__device__ __forceinline__ uint64_t get64(const uint32_t *__restrict__ pl, int32_t s) {
-    int32_t w = s >> 5;
-    uint32_t b = (uint32_t)s & 31u;
-    uint64_t lo = (uint64_t)pl[w] | ((uint64_t)pl[w + 1] << 32);
-    uint64_t hi = pl[w + 2];
-    return b ? (lo >> b) | (hi << (64 - b)) : lo;
+// seed-start validity of 32 starts in the role the view was made for
+__device__ __forceinline__ uint32_t seedvalid32(const StrandView &v, int32_t s, uint32_t sv_from_window) {
+    return v.svt ? get32(v.svt, s) : sv_from_window;
 }
-__device__ __forceinline__ uint32_t getbit(const uint32_t *__restrict__ pl, int32_t s) {
-    return (pl[s >> 5] >> ((uint32_t)s & 31u)) & 1u;
+// the three base bits at one position
+struct Base1 { uint32_t lo, hi, nm; };
+__device__ __forceinline__ Base1 base_at(const StrandView &v, int32_t s) {
+    const uint4 a = v.pw[s >> 5];
+    const uint32_t b = (uint32_t)s & 31u;
+    return Base1{(a.x >> b) & 1u, (a.y >> b) & 1u, (a.z >> b) & 1u};
 }
 
 // HOXD70 + N = -100 (lastz fill_score) from the difference planes: dl/dh = xor of the lo/hi
@@ -34,11 +64,10 @@ __device__ __forceinline__ int32_t sub_score(uint32_t dl, uint32_t dh, uint32_t 
 // substitution score and match flag of target base pt against query base pq
 __device__ __forceinline__ int32_t pair_score(const StrandView &T, const StrandView &Q, int32_t pt, int32_t pq,
                                               bool *is_match) {
-    uint32_t tlo = getbit(T.lo, pt), thi = getbit(T.hi, pt);
-    uint32_t dl = tlo ^ getbit(Q.lo, pq), dh = thi ^ getbit(Q.hi, pq);
-    uint32_t nn = getbit(T.nm, pt) | getbit(Q.nm, pq);
+    const Base1 a = base_at(T, pt), b = base_at(Q, pq);
+    const uint32_t dl = a.lo ^ b.lo, dh = a.hi ^ b.hi, nn = a.nm | b.nm;
     *is_match = !(dl | dh | nn);
-    return sub_score(dl, dh, tlo ^ thi, nn);
+    return sub_score(dl, dh, a.lo ^ a.hi, nn);
 }
 
 }  // namespace mimeo

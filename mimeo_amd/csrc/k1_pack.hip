@@ -6,11 +6,9 @@
 
 namespace mimeo {
 
-// one thread per output word (32 bases)
-__global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, int reverse,
-                               uint32_t *__restrict__ lo, uint32_t *__restrict__ hi,
-                               uint32_t *__restrict__ nm, uint32_t *__restrict__ lower,
-                               uint32_t nwords, uint32_t *__restrict__ any_lower) {
+// one thread per output word (32 bases): writes the lo/hi/nm components of pw[w]
+__global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, int reverse, uint4 *__restrict__ pw,
+                               uint32_t *__restrict__ lower, uint32_t nwords, uint32_t *__restrict__ any_lower) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     uint32_t vlo = 0, vhi = 0, vnm = 0, vlow = 0;
@@ -36,21 +34,20 @@ __global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, 
         }
         vlow |= low << b;
     }
-    lo[w] = vlo;
-    hi[w] = vhi;
-    nm[w] = vnm;
+    pw[w] = make_uint4(vlo, vhi, vnm, 0u);
     if (lower) {
         lower[w] = vlow;
         if (vlow) atomicOr(any_lower, 1u);
     }
 }
 
-// sv bit p = 1 iff p + 19 <= len and no bad base in [p, p+19); bad = nm | lower (lower may be null)
-__global__ void k1_seed_valid(const uint32_t *__restrict__ nm, const uint32_t *__restrict__ lower,
-                              uint32_t len, uint32_t nwords, uint32_t *__restrict__ sv) {
+// sv bit p = 1 iff p + 19 <= len and no bad base in [p, p+19); bad = nm | lower (lower may be
+// null).  Writes pw[w].w (out == null) or a plain plane out[w].
+__global__ void k1_seed_valid(uint4 *__restrict__ pw, const uint32_t *__restrict__ lower, uint32_t len,
+                              uint32_t nwords, uint32_t *__restrict__ out) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
-    uint64_t bad = (uint64_t)nm[w] | ((uint64_t)nm[w + 1] << 32);  // word nwords is padding (zero)
+    uint64_t bad = (uint64_t)pw[w].z | ((uint64_t)pw[w + 1].z << 32);  // word nwords is padding (zero)
     if (lower) bad |= (uint64_t)lower[w] | ((uint64_t)lower[w + 1] << 32);
     uint64_t b1 = bad | (bad >> 1);
     uint64_t b2 = b1 | (b1 >> 2);
@@ -65,31 +62,29 @@ __global__ void k1_seed_valid(const uint32_t *__restrict__ nm, const uint32_t *_
         uint32_t lastp = len - SEED_LEN;  // inclusive
         if (lastp - base < 31) ok &= (2u << (lastp - base)) - 1u;
     }
-    sv[w] = ok;
+    if (out) out[w] = ok;
+    else reinterpret_cast<uint32_t *>(&pw[w])[3] = ok;
 }
 
 static int alloc_strand(Strand &s, uint32_t len) {
     s.len = len;
     s.nwords = (len + 31) / 32;
     size_t per = (size_t)s.nwords + 2 * PLANE_PAD;
-    HIP_TRY(hipMalloc((void **)&s.base, per * 4 * sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(s.base, 0, per * 4 * sizeof(uint32_t), stream()));
+    HIP_TRY(hipMalloc((void **)&s.base, per * sizeof(uint4)));
+    HIP_TRY(hipMemsetAsync(s.base, 0, per * sizeof(uint4), stream()));
     return 0;
 }
 
 StrandView Strand::view(bool as_target) const {
-    size_t per = (size_t)nwords + 2 * PLANE_PAD;
     StrandView v;
-    v.lo = base + PLANE_PAD;
-    v.hi = base + per + PLANE_PAD;
-    v.nm = base + 2 * per + PLANE_PAD;
-    v.sv = (as_target && sv_target) ? sv_target + PLANE_PAD : base + 3 * per + PLANE_PAD;
+    v.pw = base + PLANE_PAD;
+    v.svt = (as_target && sv_target) ? sv_target + PLANE_PAD : nullptr;
     v.len = len;
     return v;
 }
 
 int pack_scaffold(const uint8_t *d_ascii, uint64_t len64, Scaffold &out) {
-    if (len64 > 0xFFFFFF00ull) { set_error("scaffold longer than 2^32-256 bases"); return MIMEO_ERR_LIMIT; }
+    if (len64 > 0x7FFFFF00ull) { set_error("scaffold longer than 2^31-256 bases"); return MIMEO_ERR_LIMIT; }
     uint32_t len = (uint32_t)len64;
     out.len = len64;
     int rc;
@@ -103,15 +98,12 @@ int pack_scaffold(const uint8_t *d_ascii, uint64_t len64, Scaffold &out) {
     HIP_TRY(hipMemsetAsync(d_lower, 0, per * sizeof(uint32_t) + 64, stream()));
     d_flag = d_lower + per;
     dim3 blk(256), grd((nwords + 255) / 256);
-    StrandView f = out.fwd.view(false), r = out.rc.view(false);
-    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 0, (uint32_t *)f.lo, (uint32_t *)f.hi,
-                       (uint32_t *)f.nm, d_lower + PLANE_PAD, nwords, d_flag);
-    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 1, (uint32_t *)r.lo, (uint32_t *)r.hi,
-                       (uint32_t *)r.nm, (uint32_t *)nullptr, nwords, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f.nm, (const uint32_t *)nullptr, len, nwords,
-                       (uint32_t *)f.sv);
-    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), r.nm, (const uint32_t *)nullptr, len, nwords,
-                       (uint32_t *)r.sv);
+    uint4 *f = out.fwd.base + PLANE_PAD, *r = out.rc.base + PLANE_PAD;
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 0, f, d_lower + PLANE_PAD, nwords, d_flag);
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 1, r, (uint32_t *)nullptr, nwords,
+                       (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f, (const uint32_t *)nullptr, len, nwords, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), r, (const uint32_t *)nullptr, len, nwords, (uint32_t *)nullptr);
     uint32_t flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
@@ -120,8 +112,8 @@ int pack_scaffold(const uint8_t *d_ascii, uint64_t len64, Scaffold &out) {
         // the target role excludes soft-masked (lower-case) bases from seeding: separate sv plane
         HIP_TRY(hipMalloc((void **)&out.fwd.sv_target, per * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(out.fwd.sv_target, 0, per * sizeof(uint32_t), stream()));
-        hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f.nm, (const uint32_t *)(d_lower + PLANE_PAD), len,
-                           nwords, out.fwd.sv_target + PLANE_PAD);
+        hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f, (const uint32_t *)(d_lower + PLANE_PAD), len, nwords,
+                           out.fwd.sv_target + PLANE_PAD);
         HIP_TRY(hipStreamSynchronize(stream()));
     }
     HIP_TRY(hipFree(d_lower));

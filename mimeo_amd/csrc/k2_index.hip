@@ -26,9 +26,10 @@ __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict
                              uint32_t *__restrict__ posv, uint32_t *__restrict__ hist) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
-    uint64_t lo = (uint64_t)s.lo[w] | ((uint64_t)s.lo[w + 1] << 32);
-    uint64_t hi = (uint64_t)s.hi[w] | ((uint64_t)s.hi[w + 1] << 32);
-    uint32_t sv = s.sv[w];
+    const uint4 a = s.pw[w], c = s.pw[w + 1];
+    uint64_t lo = (uint64_t)a.x | ((uint64_t)c.x << 32);
+    uint64_t hi = (uint64_t)a.y | ((uint64_t)c.y << 32);
+    uint32_t sv = s.svt ? s.svt[w] : a.w;
     uint32_t base = w * 32u;
 #pragma unroll 4
     for (uint32_t b = 0; b < 32; b++) {

@@ -43,99 +43,149 @@ struct Cand {
 __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandView &Q, int32_t p, int32_t d,
                                             int transitions) {
     int32_t pq = p - d;
-    if (!((get32(T.sv, p) & get32(Q.sv, pq)) & 1u)) return false;
-    uint32_t dl = (get32(T.lo, p) ^ get32(Q.lo, pq)) & CARE19;
-    uint32_t dh = (get32(T.hi, p) ^ get32(Q.hi, pq)) & CARE19;
+    const Win32 tw = win32(T, p), qw = win32(Q, pq);
+    if (!((seedvalid32(T, p, tw.sv) & qw.sv) & 1u)) return false;
+    uint32_t dl = (tw.lo ^ qw.lo) & CARE19;
+    uint32_t dh = (tw.hi ^ qw.hi) & CARE19;
     if (!transitions) return (dl | dh) == 0;
     return dl == 0 && __popc(dh) <= 1;
 }
 
 // ---- K4a: one lane per hit --------------------------------------------------------------
+// The walks advance four bases at a time through a 4096-entry LDS table indexed by the
+// (dl, dh, cg) bits of the four bases in walk order; an entry packs the group's score sum S,
+// its best prefix M (and where), and its lowest prefix mn (10 bits each).  Because four
+// HOXD70 columns can move the running score by at most 500 < xdrop, a group cannot both set a
+// new best and trigger the x-drop: "run + mn < best - xdrop" is exactly "the walk stops in this
+// group", and otherwise the group is applied in one step.  Groups holding an N, an earlier seed
+// hit, or the sequence end fall back to single bases.
+constexpr int GROUP_TAB = 4096;
+
+static inline int host_sub(int dl, int dh, int cg) {
+    static const int lo[4] = {91, 100, -31, -31}, hi[4] = {-114, -114, -123, -125};
+    return (dl ? hi : lo)[(dh << 1) | cg];
+}
+static void build_group_table(uint32_t *tab) {
+    for (int idx = 0; idx < GROUP_TAB; idx++) {
+        int p = 0, M = -100000, mn = 100000, posM = 0;
+        for (int k = 0; k < 4; k++) {
+            p += host_sub((idx >> k) & 1, (idx >> (4 + k)) & 1, (idx >> (8 + k)) & 1);
+            if (p > M) { M = p; posM = k; }
+            if (p < mn) mn = p;
+        }
+        tab[idx] = ((uint32_t)p & 0x3FFu) | (((uint32_t)M & 0x3FFu) << 10) | (((uint32_t)mn & 0x3FFu) << 20) |
+                   ((uint32_t)posM << 30);
+    }
+}
+
+struct WalkState {
+    int32_t run, best;
+    uint32_t bk, k;  // steps at the best prefix, steps done
+    bool done, found;
+    uint32_t found_step;  // step index (1-based) whose boundary carries an earlier seed hit
+};
+
+// up to 32 steps of a walk whose masks are in step order (bit s <-> step s of this window)
+__device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl, uint32_t mdh,
+                                            uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit, int xdrop) {
+    for (uint32_t pos = 0; pos < 32;) {
+        const uint32_t rem = limit - w.k;
+        if (rem == 0) { w.done = true; return; }
+        if (rem >= 4 && pos <= 28 && !(((mnn | mH) >> pos) & 0xFu)) {
+            const uint32_t idx = ((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8);
+            const uint32_t e = tab[idx];
+            const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
+            if (w.run + mn < w.best - xdrop) { w.done = true; return; }
+            if (w.run + M > w.best) { w.best = w.run + M; w.bk = w.k + (e >> 30) + 1; }
+            w.run += S;
+            w.k += 4;
+            pos += 4;
+        } else {
+            w.k++;
+            w.run += sub_score((mdl >> pos) & 1u, (mdh >> pos) & 1u, (mcg >> pos) & 1u, (mnn >> pos) & 1u);
+            if (w.run > w.best) { w.best = w.run; w.bk = w.k; }
+            if (w.run < w.best - xdrop) { w.done = true; return; }
+            if ((mH >> pos) & 1u) { w.found = true; w.found_step = w.k; w.done = true; return; }
+            pos++;
+        }
+    }
+}
+
 __global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
                                                               const uint2 *__restrict__ hits, uint64_t nhits,
                                                               int xdrop, int hspthresh, int transitions,
+                                                              const uint32_t *__restrict__ group_tab,
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                               uint64_t cand_cap, uint64_t *__restrict__ fkey,
                                                               uint32_t *__restrict__ fprev,
                                                               uint2 *__restrict__ longq) {
-    uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
-    if (gid >= nhits) return;
-    uint2 h = hits[gid];
-    const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
-    const int32_t d = (int32_t)h.x - (int32_t)h.y;
-    // ---- left walk, with detection of an earlier seed hit at every reached boundary
-    int32_t run = 0, best = 0;
-    uint32_t bl = 0, k = 0;
-    const uint32_t maxl = (uint32_t)min(et, eq);
-    bool done = false, found = false, is_long = false;
-    uint32_t prev_end = 0;
-    for (int win = 0; !done; win++) {
-        if (win == LONG_WINDOWS) { is_long = true; break; }
-        int32_t P = et - 32 * (win + 1) - SEED_LEN, Pq = P - d;
-        uint64_t tlo = get64(T.lo, P), thi = get64(T.hi, P);
-        uint64_t dl64 = tlo ^ get64(Q.lo, Pq), dh64 = thi ^ get64(Q.hi, Pq);
-        uint64_t nm = dl64 | dh64, ones = 0, twos = 0, tv = 0;
+    __shared__ uint32_t tab[GROUP_TAB];
+    for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
+    __syncthreads();
+    for (uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x; gid < nhits;
+         gid += (uint64_t)gridDim.x * EXT_THREADS) {
+        const uint2 h = hits[gid];
+        const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
+        const int32_t d = (int32_t)h.x - (int32_t)h.y;
+        // ---- left walk, with detection of an earlier seed hit at every reached boundary
+        WalkState L{0, 0, 0, 0, false, false, 0};
+        const uint32_t maxl = (uint32_t)min(et, eq);
+        bool is_long = false;
+        for (int win = 0; !L.done; win++) {
+            if (win == LONG_WINDOWS) { is_long = true; break; }
+            const int32_t P = et - 32 * (win + 1) - SEED_LEN, Pq = P - d;
+            const Win64 tw = win64(T, P), qw = win64(Q, Pq);
+            const uint64_t dl64 = tw.lo ^ qw.lo, dh64 = tw.hi ^ qw.hi, nm64 = dl64 | dh64;
+            const uint32_t nlo = (uint32_t)nm64, nhi = (uint32_t)(nm64 >> 32);
+            const uint32_t tlo = (uint32_t)dl64, thi = (uint32_t)(dl64 >> 32);
+            // seed hits among the 32 starts P .. P+31: care positions carry at most one non-match,
+            // and it must be a transition (dl = 0)
+            uint32_t ones = 0, twos = 0, tv = 0;
 #pragma unroll
-        for (int c = 0; c < SEED_LEN; c++) {
-            if (!((CARE19 >> c) & 1u)) continue;
-            uint64_t v = nm >> c;
-            twos |= ones & v;
-            ones |= v;
-            tv |= dl64 >> c;
+            for (int c = 0; c < SEED_LEN; c++) {
+                if (!((CARE19 >> c) & 1u)) continue;
+                const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
+                twos |= ones & v;
+                ones |= v;
+                tv |= c ? __builtin_amdgcn_alignbit(thi, tlo, c) : tlo;
+            }
+            const uint32_t bad = transitions ? (twos | tv) : ones;
+            const uint32_t H = ~bad & seedvalid32(T, P, (uint32_t)tw.sv) & (uint32_t)qw.sv;
+            // walk bits in step order: step s <-> position P + 19 + 31 - s
+            walk_window(tab, L, __brev((uint32_t)(dl64 >> SEED_LEN)), __brev((uint32_t)(dh64 >> SEED_LEN)),
+                        __brev((uint32_t)((tw.lo ^ tw.hi) >> SEED_LEN)), __brev((uint32_t)((tw.nm | qw.nm) >> SEED_LEN)),
+                        __brev(H), maxl, xdrop);
         }
-        uint64_t bad = transitions ? (twos | tv) : ones;
-        uint32_t H = ~(uint32_t)bad & get32(T.sv, P) & get32(Q.sv, Pq);
-        uint32_t wdl = (uint32_t)(dl64 >> SEED_LEN), wdh = (uint32_t)(dh64 >> SEED_LEN);
-        uint32_t wcg = (uint32_t)((tlo ^ thi) >> SEED_LEN);
-        uint32_t wnn = get32(T.nm, P + SEED_LEN) | get32(Q.nm, Pq + SEED_LEN);
-        for (int b = 31; b >= 0; b--) {
-            if (k >= maxl) { done = true; break; }
-            k++;
-            run += sub_score((wdl >> b) & 1u, (wdh >> b) & 1u, (wcg >> b) & 1u, (wnn >> b) & 1u);
-            if (run > best) { best = run; bl = k; }
-            if (run < best - xdrop) { done = true; break; }
-            if ((H >> b) & 1u) { found = true; prev_end = (uint32_t)(P + SEED_LEN + b); done = true; break; }
+        if (is_long) {
+            unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
+            longq[i] = h;
+            continue;
         }
-    }
-    if (is_long) {
-        unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
-        longq[i] = h;
-        return;
-    }
-    if (found) {
-        unsigned long long i = atomicAdd(&ctr->nfollow, 1ull);
-        fkey[i] = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
-        fprev[i] = prev_end;
-        return;
-    }
-    // ---- right walk
-    int32_t runr = 0, bestr = 0;
-    uint32_t br = 0, kr = 0;
-    const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
-    done = false;
-    for (int win = 0; !done; win++) {
-        if (win == LONG_WINDOWS) { is_long = true; break; }
-        int32_t P = et + 32 * win, Pq = P - d;
-        uint32_t tlo = get32(T.lo, P), thi = get32(T.hi, P);
-        uint32_t wdl = tlo ^ get32(Q.lo, Pq), wdh = thi ^ get32(Q.hi, Pq), wcg = tlo ^ thi;
-        uint32_t wnn = get32(T.nm, P) | get32(Q.nm, Pq);
-        for (int b = 0; b < 32; b++) {
-            if (kr >= maxr) { done = true; break; }
-            kr++;
-            runr += sub_score((wdl >> b) & 1u, (wdh >> b) & 1u, (wcg >> b) & 1u, (wnn >> b) & 1u);
-            if (runr > bestr) { bestr = runr; br = kr; }
-            if (runr < bestr - xdrop) { done = true; break; }
+        if (L.found) {
+            unsigned long long i = atomicAdd(&ctr->nfollow, 1ull);
+            fkey[i] = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
+            fprev[i] = (uint32_t)et - L.found_step;  // position of the base just summed = that seed's end
+            continue;
         }
-    }
-    if (is_long) {
-        unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
-        longq[i] = h;
-        return;
-    }
-    int32_t score = best + bestr;
-    if (score >= hspthresh) {
-        unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
-        if (i < cand_cap) cand[i] = Cand{(uint32_t)et - bl, (uint32_t)eq - bl, bl + br, score};
+        // ---- right walk
+        WalkState R{0, 0, 0, 0, false, false, 0};
+        const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
+        for (int win = 0; !R.done; win++) {
+            if (win == LONG_WINDOWS) { is_long = true; break; }
+            const int32_t P = et + 32 * win, Pq = P - d;
+            const Win32 tw = win32(T, P), qw = win32(Q, Pq);
+            walk_window(tab, R, tw.lo ^ qw.lo, tw.hi ^ qw.hi, tw.lo ^ tw.hi, tw.nm | qw.nm, 0u, maxr, xdrop);
+        }
+        if (is_long) {
+            unsigned long long i = atomicAdd(&ctr->nlong, 1ull);
+            longq[i] = h;
+            continue;
+        }
+        const int32_t score = L.best + R.best;
+        if (score >= hspthresh) {
+            unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
+            if (i < cand_cap) cand[i] = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, score};
+        }
     }
 }
 
@@ -179,10 +229,8 @@ __device__ WalkResult wave_walk(const StrandView &T, const StrandView &Q, int32_
         int32_t pq = pt - d;
         int64_t s = 0;
         if (active) {
-            uint32_t tlo = get32(T.lo, pt) & 1u, thi = get32(T.hi, pt) & 1u;
-            uint32_t dl = tlo ^ (get32(Q.lo, pq) & 1u), dh = thi ^ (get32(Q.hi, pq) & 1u);
-            uint32_t nn = (get32(T.nm, pt) | get32(Q.nm, pq)) & 1u;
-            s = sub_score(dl, dh, tlo ^ thi, nn);
+            const Base1 ta = base_at(T, pt), qa = base_at(Q, pq);
+            s = sub_score(ta.lo ^ qa.lo, ta.hi ^ qa.hi, ta.lo ^ ta.hi, ta.nm | qa.nm);
         }
         int64_t P = run + wave_incl_sum(s, lane);
         int64_t M = max(r.best, wave_incl_max(P, lane));
@@ -231,9 +279,9 @@ __device__ WalkResult wave_walk_fast(const StrandView &T, const StrandView &Q, i
         if (nst) {
             // bit b of every mask <-> step off + b
             int32_t pt = dir > 0 ? et + (int32_t)off : et - (int32_t)off - 32, pq = pt - d;
-            uint32_t tlo = get32(T.lo, pt), thi = get32(T.hi, pt);
-            dl = tlo ^ get32(Q.lo, pq); dh = thi ^ get32(Q.hi, pq); cg = tlo ^ thi;
-            nn = get32(T.nm, pt) | get32(Q.nm, pq);
+            const Win32 tw = win32(T, pt), qw = win32(Q, pq);
+            dl = tw.lo ^ qw.lo; dh = tw.hi ^ qw.hi; cg = tw.lo ^ tw.hi;
+            nn = tw.nm | qw.nm;
             if (dir < 0) { dl = __brev(dl); dh = __brev(dh); cg = __brev(cg); nn = __brev(nn); }
         }
         const uint32_t valid = nst == 32 ? 0xFFFFFFFFu : ((1u << nst) - 1u);
@@ -354,7 +402,6 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T,
                                                                    Cand *__restrict__ cand, uint64_t cand_cap) {
     uint64_t sid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
     if (sid >= nseg) return;
-    const uint32_t lane = threadIdx.x & 63u;
     uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
     uint64_t k0 = key[beg];
     const int32_t d = (int32_t)(uint32_t)(k0 >> 32) - (int32_t)Q.len;
@@ -395,8 +442,9 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
         int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
         for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 64u * 32u) {
             int32_t pt = (int32_t)(c.tstart + w0), pq = pt - d;
-            uint32_t tlo = get32(T.lo, pt), thi = get32(T.hi, pt);
-            uint32_t m = ~((tlo ^ get32(Q.lo, pq)) | (thi ^ get32(Q.hi, pq))) & ~(get32(T.nm, pt) | get32(Q.nm, pq));
+            const Win32 tw = win32(T, pt), qw = win32(Q, pq);
+            const uint32_t tlo = tw.lo, thi = tw.hi;
+            uint32_t m = ~((tlo ^ qw.lo) | (thi ^ qw.hi)) & ~(tw.nm | qw.nm);
             uint32_t rem = c.len - w0;
             if (rem < 32) m &= (1u << rem) - 1u;
             cnt[0] += __popc(m & ~tlo & ~thi);
@@ -428,6 +476,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
 // ---- host orchestration ---------------------------------------------------------------------
 struct ExtWork {
     ExtCounters *ctr = nullptr;  // device
+    uint32_t *group_tab = nullptr;  // device copy of the 4-base group table
     DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, flags, segs, tmp, nsel;
 };
 static ExtWork W;
@@ -438,6 +487,12 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
     *nhsp = 0;
     if (T.len >= 0x7FFFFF00u || Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
     if (!W.ctr) HIP_TRY(hipMalloc((void **)&W.ctr, sizeof(ExtCounters)));
+    if (!W.group_tab) {
+        std::vector<uint32_t> tab(GROUP_TAB);
+        build_group_table(tab.data());
+        HIP_TRY(hipMalloc((void **)&W.group_tab, GROUP_TAB * 4));
+        HIP_TRY(hipMemcpy(W.group_tab, tab.data(), GROUP_TAB * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
     if (!nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
     hipEvent_t e0, e1;
@@ -454,9 +509,10 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
         if ((rc = W.longq.reserve(nhits * 8))) return rc;
         HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
         uint64_t nb = (nhits + EXT_THREADS - 1) / EXT_THREADS;
+        if (nb > 256 * 32) nb = 256 * 32;  // grid-stride: the LDS table is loaded once per workgroup
         hipLaunchKernelGGL(k4_extend_hits, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
-                           p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
-                           (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+                           p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
+                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
         HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (c.nlong) {

@@ -57,12 +57,14 @@ __device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int
     if (jb > lenB) { qlo = qhi = qn = 0; return; }
     if (dir > 0) {
         int32_t p = (int32_t)(aq + jb) - 1;
-        qlo = get32(Q.lo, p) & SMASK; qhi = get32(Q.hi, p) & SMASK; qn = get32(Q.nm, p) & SMASK;
+        const Win32 w = win32(Q, p);
+        qlo = w.lo & SMASK; qhi = w.hi & SMASK; qn = w.nm & SMASK;
     } else {
         // bit t <-> position p + t <-> column jb + WSTRIP - 1 - t
         int32_t p = (int32_t)aq - (int32_t)jb - (WSTRIP - 1);
-        qlo = __brev(get32(Q.lo, p) & SMASK) >> (32 - WSTRIP); qhi = __brev(get32(Q.hi, p) & SMASK) >> (32 - WSTRIP);
-        qn = __brev(get32(Q.nm, p) & SMASK) >> (32 - WSTRIP);
+        const Win32 w = win32(Q, p);
+        qlo = __brev(w.lo & SMASK) >> (32 - WSTRIP); qhi = __brev(w.hi & SMASK) >> (32 - WSTRIP);
+        qn = __brev(w.nm & SMASK) >> (32 - WSTRIP);
     }
 }
 
@@ -81,9 +83,9 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         for (uint32_t k0 = 0; k0 < n; k0 += 64u * 32u) {
             uint32_t k = k0 + lane * 32u;
             if (k < n) {
-                uint32_t tlo = get32(T.lo, st + (int32_t)k), thi = get32(T.hi, st + (int32_t)k);
-                uint32_t bad = (tlo ^ get32(Q.lo, sq + (int32_t)k)) | (thi ^ get32(Q.hi, sq + (int32_t)k)) |
-                               get32(T.nm, st + (int32_t)k) | get32(Q.nm, sq + (int32_t)k);
+                const Win32 tw = win32(T, st + (int32_t)k), qw = win32(Q, sq + (int32_t)k);
+                const uint32_t tlo = tw.lo, thi = tw.hi;
+                uint32_t bad = (tlo ^ qw.lo) | (thi ^ qw.hi) | tw.nm | qw.nm;
                 uint32_t rem = n - k, mask = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
                 if (bad & mask) ok = false;
                 ncg += __popc((tlo ^ thi) & mask);
@@ -118,7 +120,8 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
     for (uint32_t i = 1; i <= lenA; i++) {
         const int32_t thr = best.score - Y;
         const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
-        const uint32_t alo = getbit(T.lo, pa), ahi = getbit(T.hi, pa), an = getbit(T.nm, pa), acg = alo ^ ahi;
+        const Base1 ab = base_at(T, pa);
+        const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
         // C of the column left of my strip (previous row): last slot of the previous lane in ring order
         Cell p7{Cs[WSTRIP - 1], Cm[WSTRIP - 1], Cx[WSTRIP - 1]};
         p7 = shfl_cell(p7, (int)((lane + 63u) & 63u));
@@ -381,8 +384,8 @@ __global__ __launch_bounds__(256) void k6_ungapped(Group *__restrict__ groups, c
         uint32_t nmatch = 0;
         for (uint32_t w0 = lane * 32u; w0 < h.length; w0 += 64u * 32u) {
             int32_t pt = (int32_t)(h.tstart + w0), pq = pt - d;
-            uint32_t mm = ~((get32(G.T.lo, pt) ^ get32(G.Q.lo, pq)) | (get32(G.T.hi, pt) ^ get32(G.Q.hi, pq))) &
-                          ~(get32(G.T.nm, pt) | get32(G.Q.nm, pq));
+            const Win32 tw = win32(G.T, pt), qw = win32(G.Q, pq);
+            uint32_t mm = ~((tw.lo ^ qw.lo) | (tw.hi ^ qw.hi)) & ~(tw.nm | qw.nm);
             uint32_t rem = h.length - w0;
             if (rem < 32) mm &= (1u << rem) - 1u;
             nmatch += __popc(mm);
