@@ -18,6 +18,7 @@
 //   * walks longer than LONG_CAP bases are finished by k4_extend_long, one wavefront per hit,
 //     64 bases per step with wave-level prefix sums.
 //   * k4_entropy applies the entropy adjustment to candidates and the threshold.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -31,7 +32,7 @@ constexpr int EXT_THREADS = 256;
 constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per direction
 
 struct ExtCounters {
-    unsigned long long ncand, nfollow, nlong, nhsp;
+    unsigned long long ncand, nfollow, nlong, nhsp, nmed;
 };
 
 struct Cand {
@@ -60,6 +61,7 @@ __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandVie
 // group", and otherwise the group is applied in one step.  Groups holding an N, an earlier seed
 // hit, or the sequence end fall back to single bases.
 constexpr int GROUP_TAB = 4096;
+constexpr int QCAP = 128;  // per-wave staging capacity of the K4a output queues
 
 static inline int host_sub(int dl, int dh, int cg) {
     static const int lo[4] = {91, 100, -31, -31}, hi[4] = {-114, -114, -123, -125};
@@ -87,8 +89,9 @@ struct WalkState {
 
 // up to 32 steps of a walk whose masks are in step order (bit s <-> step s of this window)
 __device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl, uint32_t mdh,
-                                            uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit, int xdrop) {
-    for (uint32_t pos = 0; pos < 32;) {
+                                            uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit, int xdrop,
+                                            uint32_t start = 0) {
+    for (uint32_t pos = start; pos < 32;) {
         const uint32_t rem = limit - w.k;
         if (rem == 0) { w.done = true; return; }
         if (rem >= 4 && pos <= 28 && !(((mnn | mH) >> pos) & 0xFu)) {
@@ -111,7 +114,7 @@ __device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, Wa
     }
 }
 
-__global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
+__global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, StrandView Q,
                                                               const uint2 *__restrict__ hits, uint64_t nhits,
                                                               int xdrop, int hspthresh, int transitions,
                                                               const uint32_t *__restrict__ group_tab,
@@ -186,6 +189,221 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, Stra
             unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
             if (i < cand_cap) cand[i] = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, score};
         }
+    }
+}
+
+// The same 32 steps as walk_window, as straight-line predicated code: eight table groups, no
+// per-lane branches.  A lane whose next group holds an N, an earlier seed hit or the sequence end
+// stops here and finishes the window in walk_window (rare; taken under a wave-uniform branch).
+__device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl,
+                                                 uint32_t mdh, uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit,
+                                                 int xdrop) {
+    bool act = !w.done, slow = false;
+    uint32_t slow_pos = 0;
+    const uint32_t blocked = mnn | mH;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int pos = 4 * c;
+        const bool can = act && (limit - w.k >= 4u) && !((blocked >> pos) & 0xFu);
+        if (act && !can) { slow = true; slow_pos = pos; }
+        act = act && can;
+        const uint32_t idx = ((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8);
+        const uint32_t e = tab[idx];
+        const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
+        const bool brk = act && (w.run + mn < w.best - xdrop);
+        const bool go = act && !brk;
+        const bool upd = go && (w.run + M > w.best);
+        w.bk = upd ? w.k + (e >> 30) + 1 : w.bk;
+        w.best = upd ? w.run + M : w.best;
+        w.run = go ? w.run + S : w.run;
+        w.k = go ? w.k + 4 : w.k;
+        w.done = w.done || brk;
+        act = go;
+    }
+    if (__ballot(slow)) {
+        if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, slow_pos);
+    }
+}
+
+// ---- K4a fast path: the whole neighbourhood of a hit is loaded once ---------------------------
+// A random hit dies within ~45 bases to the left of its seed end and ~20 to the right.  The fast
+// kernel therefore loads, per lane, six interleaved words of the target around the seed start and
+// seven of the query (13 16-byte loads issued back to back, 2-3 cache lines per sequence), shifts
+// the query into the target's bit frame once, and serves two left windows (64 bases) and two
+// right windows (64 bases) from registers with compile-time word indices.  A walk that is still
+// alive beyond that goes to the generic kernel through a queue (a few per cent of random hits,
+// plus hits inside real similarity).
+__device__ __forceinline__ uint32_t ext32(uint32_t a, uint32_t b, uint32_t c, uint32_t sh) {
+    return sh < 32 ? __builtin_amdgcn_alignbit(b, a, sh) : __builtin_amdgcn_alignbit(c, b, sh - 32);
+}
+
+struct Frame {
+    uint32_t dl[6], dh[6], cg[6], nn[6], st[6], sq[6];  // difference / class planes in the target's bit frame
+};
+
+template <int WIN>
+__device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, const Frame &F, uint32_t bt,
+                                            int transitions, WalkState &L, uint32_t maxl, int xdrop) {
+    constexpr int b = 1 - WIN;  // word holding seed start - 32*(WIN+1)
+    const uint32_t dllo = __builtin_amdgcn_alignbit(F.dl[b + 1], F.dl[b], bt), dlhi = __builtin_amdgcn_alignbit(F.dl[b + 2], F.dl[b + 1], bt);
+    const uint32_t dhlo = __builtin_amdgcn_alignbit(F.dh[b + 1], F.dh[b], bt), dhhi = __builtin_amdgcn_alignbit(F.dh[b + 2], F.dh[b + 1], bt);
+    const uint32_t cglo = __builtin_amdgcn_alignbit(F.cg[b + 1], F.cg[b], bt), cghi = __builtin_amdgcn_alignbit(F.cg[b + 2], F.cg[b + 1], bt);
+    const uint32_t nnlo = __builtin_amdgcn_alignbit(F.nn[b + 1], F.nn[b], bt), nnhi = __builtin_amdgcn_alignbit(F.nn[b + 2], F.nn[b + 1], bt);
+    const uint32_t nlo = dllo | dhlo, nhi = dlhi | dhhi;
+    uint32_t ones = 0, twos = 0, tv = 0;
+#pragma unroll
+    for (int c = 0; c < SEED_LEN; c++) {
+        if (!((CARE19 >> c) & 1u)) continue;
+        const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
+        twos |= ones & v;
+        ones |= v;
+        tv |= c ? __builtin_amdgcn_alignbit(dlhi, dllo, c) : dllo;
+    }
+    const uint32_t bad = transitions ? (twos | tv) : ones;
+    const uint32_t H = ~bad & __builtin_amdgcn_alignbit(F.st[b + 1], F.st[b], bt) & __builtin_amdgcn_alignbit(F.sq[b + 1], F.sq[b], bt);
+    walk_window_pred(tab, L, __brev(__builtin_amdgcn_alignbit(dlhi, dllo, SEED_LEN)), __brev(__builtin_amdgcn_alignbit(dhhi, dhlo, SEED_LEN)),
+                __brev(__builtin_amdgcn_alignbit(cghi, cglo, SEED_LEN)), __brev(__builtin_amdgcn_alignbit(nnhi, nnlo, SEED_LEN)),
+                __brev(H), maxl, xdrop);
+}
+
+template <int VARIANT>  // 1 = production; 2 = loads only, 3 = compute only (timing experiments, wrong results)
+__global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
+                                                              const uint2 *__restrict__ hits, uint64_t nhits,
+                                                              int xdrop, int hspthresh, int transitions,
+                                                              const uint32_t *__restrict__ group_tab,
+                                                              ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
+                                                              uint64_t cand_cap, uint64_t *__restrict__ fkey,
+                                                              uint32_t *__restrict__ fprev,
+                                                              uint2 *__restrict__ medq) {
+    __shared__ uint32_t tab[GROUP_TAB];
+    // per-wave staging of the three output queues: one global atomic per >= 64 records instead of
+    // one per wavefront iteration (same-address atomics serialise at ~15 ns each)
+    __shared__ uint2 s_med[EXT_THREADS / 64][QCAP];
+    __shared__ uint64_t s_fk[EXT_THREADS / 64][QCAP];
+    __shared__ uint32_t s_fp[EXT_THREADS / 64][QCAP];
+    __shared__ Cand s_cd[EXT_THREADS / 64][QCAP];
+    for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_med = 0, n_fol = 0, n_cd = 0;  // wave-uniform fill levels
+    const uint64_t stride = (uint64_t)gridDim.x * EXT_THREADS;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * EXT_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
+        const uint64_t gid = g0 + lane;
+        bool q_med = false, q_fol = false, q_cd = false;
+        uint2 h = make_uint2(0, 0);
+        uint64_t r_fk = 0;
+        uint32_t r_fp = 0;
+        Cand r_cd{0, 0, 0, 0};
+        if (gid < nhits) {
+        h = hits[gid];
+        const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
+        const int32_t d = (int32_t)h.x - (int32_t)h.y;
+        const uint32_t bt = h.x & 31u, bq = h.y & 31u, sh = (bq - bt) & 31u;
+        const int32_t wt = (int32_t)(h.x >> 5) - 2, wq = (int32_t)(h.y >> 5) - 2 - (bq < bt ? 1 : 0);
+        uint4 tw[6], qw[7];
+        if (VARIANT == 3) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) tw[k] = make_uint4(h.x * (k + 1), h.y + k, 0, ~0u);
+#pragma unroll
+            for (int k = 0; k < 7; k++) qw[k] = make_uint4(h.y * (k + 3), h.x + k, 0, ~0u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) tw[k] = T.pw[wt + k];
+#pragma unroll
+            for (int k = 0; k < 7; k++) qw[k] = Q.pw[wq + k];
+        }
+        if (VARIANT == 2) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc ^= tw[k].x ^ tw[k].y ^ tw[k].z ^ tw[k].w ^ qw[k].x ^ qw[k].y ^ qw[k].z ^ qw[k].w;
+            acc ^= qw[6].x ^ qw[6].y ^ qw[6].z ^ qw[6].w;
+            if (acc == 0x12345678u) q_med = true;
+        } else {
+        Frame F;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t qlo = __builtin_amdgcn_alignbit(qw[k + 1].x, qw[k].x, sh), qhi = __builtin_amdgcn_alignbit(qw[k + 1].y, qw[k].y, sh);
+            F.dl[k] = tw[k].x ^ qlo;
+            F.dh[k] = tw[k].y ^ qhi;
+            F.cg[k] = tw[k].x ^ tw[k].y;
+            F.nn[k] = tw[k].z | __builtin_amdgcn_alignbit(qw[k + 1].z, qw[k].z, sh);
+            F.st[k] = T.svt ? T.svt[wt + k] : tw[k].w;
+            F.sq[k] = __builtin_amdgcn_alignbit(qw[k + 1].w, qw[k].w, sh);
+        }
+        // ---- left walk: up to two windows from the frame (the seed starts at frame bit 64 + bt)
+        WalkState L{0, 0, 0, 0, false, false, 0};
+        const uint32_t maxl = (uint32_t)min(et, eq);
+        left_window<0>(tab, F, bt, transitions, L, maxl, xdrop);
+        if (!L.done) left_window<1>(tab, F, bt, transitions, L, maxl, xdrop);
+        if (!L.done) {  // still alive after 64 bases: generic kernel
+            q_med = true;
+        } else if (L.found) {
+            q_fol = true;
+            r_fk = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
+            r_fp = (uint32_t)et - L.found_step;
+        } else {
+        // ---- right walk: two windows from the frame (frame bit of the seed end = 64 + bt + 19)
+        WalkState R{0, 0, 0, 0, false, false, 0};
+        const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
+        const uint32_t rs = bt + SEED_LEN;
+        walk_window_pred(tab, R, ext32(F.dl[2], F.dl[3], F.dl[4], rs), ext32(F.dh[2], F.dh[3], F.dh[4], rs),
+                    ext32(F.cg[2], F.cg[3], F.cg[4], rs), ext32(F.nn[2], F.nn[3], F.nn[4], rs), 0u, maxr, xdrop);
+        if (!R.done)
+            walk_window_pred(tab, R, ext32(F.dl[3], F.dl[4], F.dl[5], rs), ext32(F.dh[3], F.dh[4], F.dh[5], rs),
+                        ext32(F.cg[3], F.cg[4], F.cg[5], rs), ext32(F.nn[3], F.nn[4], F.nn[5], rs), 0u, maxr, xdrop);
+        if (!R.done) {
+            q_med = true;
+        } else if (L.best + R.best >= hspthresh) {
+            q_cd = true;
+            r_cd = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best};
+        }
+        }  // right walk
+        }  // VARIANT != 2
+        }  // gid < nhits
+        // ---- stage the records; flush a queue with one atomic once it holds >= 64
+        uint64_t m = __ballot(q_med);
+        if (m) {
+            if (q_med) s_med[wv][n_med + __popcll(m & lt_mask)] = h;
+            n_med += __popcll(m);
+        }
+        m = __ballot(q_fol);
+        if (m) {
+            if (q_fol) { uint32_t i = n_fol + __popcll(m & lt_mask); s_fk[wv][i] = r_fk; s_fp[wv][i] = r_fp; }
+            n_fol += __popcll(m);
+        }
+        m = __ballot(q_cd);
+        if (m) {
+            if (q_cd) s_cd[wv][n_cd + __popcll(m & lt_mask)] = r_cd;
+            n_cd += __popcll(m);
+        }
+        const bool last = g0 + stride >= nhits;
+        if (n_med >= 64 || (last && n_med)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
+            b = __shfl(b, 0);
+            for (uint32_t i = lane; i < n_med; i += 64) medq[b + i] = s_med[wv][i];
+            n_med = 0;
+        }
+        if (n_fol >= 64 || (last && n_fol)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
+            b = __shfl(b, 0);
+            for (uint32_t i = lane; i < n_fol; i += 64) { fkey[b + i] = s_fk[wv][i]; fprev[b + i] = s_fp[wv][i]; }
+            n_fol = 0;
+        }
+        if (n_cd >= 64 || (last && n_cd)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
+            b = __shfl(b, 0);
+            for (uint32_t i = lane; i < n_cd; i += 64)
+                if (b + i < cand_cap) cand[b + i] = s_cd[wv][i];
+            n_cd = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 }
 
@@ -477,7 +695,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
 struct ExtWork {
     ExtCounters *ctr = nullptr;  // device
     uint32_t *group_tab = nullptr;  // device copy of the 4-base group table
-    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, flags, segs, tmp, nsel;
+    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel;
 };
 static ExtWork W;
 
@@ -507,14 +725,33 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
         if ((rc = W.fkey.reserve(nhits * 8))) return rc;
         if ((rc = W.fprev.reserve(nhits * 4))) return rc;
         if ((rc = W.longq.reserve(nhits * 8))) return rc;
+        if ((rc = W.medq.reserve(nhits * 8))) return rc;
         HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
         uint64_t nb = (nhits + EXT_THREADS - 1) / EXT_THREADS;
         if (nb > 256 * 32) nb = 256 * 32;  // grid-stride: the LDS table is loaded once per workgroup
-        hipLaunchKernelGGL(k4_extend_hits, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
-                           p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
-                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+        static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
+#define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
+                           p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
+                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p)
+        if (variant == 0)
+            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
+                               p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
+                               (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+        else if (variant == 2) K4_LAUNCH(2);
+        else if (variant == 3) K4_LAUNCH(3);
+        else K4_LAUNCH(1);
         HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (c.nmed) {
+            uint64_t nbm = (c.nmed + EXT_THREADS - 1) / EXT_THREADS;
+            if (nbm > 256 * 32) nbm = 256 * 32;
+            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)nbm), dim3(EXT_THREADS), 0, st, T, Q,
+                               (const uint2 *)W.medq.p, (uint64_t)c.nmed, p->xdrop, p->hspthresh, p->transitions,
+                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                               (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         if (c.nlong) {
             uint64_t nbl = (c.nlong * 64 + EXT_THREADS - 1) / EXT_THREADS;
             hipLaunchKernelGGL(k4_extend_long, dim3((uint32_t)nbl), dim3(EXT_THREADS), 0, st, T, Q,
