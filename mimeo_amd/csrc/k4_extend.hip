@@ -479,75 +479,102 @@ __device__ WalkResult wave_walk(const StrandView &T, const StrandView &Q, int32_
     return r;
 }
 
-// Word-granular walk without seed detection: 64 lanes x 32 bases per step.  Each lane reduces
-// its 32-base word to (sum S, best prefix M and its position, lowest prefix mn, deepest drop below
-// the running in-word maximum a); a wave prefix sum / prefix max turns these into the exact
-// running score and best at every word boundary, and the walk can only stop inside the first word
-// with  a < -xdrop  or  run_in + mn < best_in - xdrop, which that lane then replays base by base.
-// Words that are all matches (the common case on long diagonals) need no per-base loop at all.
+// Word-granular walk without seed detection: 64 lanes x 4 words x 32 bases = 8192 bases per step.
+// Each lane reduces its 128 bases to (sum S, best prefix M and its position, lowest prefix mn,
+// deepest drop a below the running in-lane maximum); a wave prefix sum / prefix max turns these
+// into the exact running score and best at every lane boundary, and the walk can only stop inside
+// the first lane with  a < -xdrop  or  run_in + mn < best_in - xdrop, which then replays its
+// bases one by one.  Words that are all matches (the common case on long diagonals) need no
+// per-base loop at all.
+constexpr int WALK_WORDS = 4;
+
 __device__ WalkResult wave_walk_fast(const StrandView &T, const StrandView &Q, int32_t et, int32_t d, int dir,
                                      uint32_t maxsteps, int xdrop) {
     const uint32_t lane = threadIdx.x & 63u;
     WalkResult r{0, 0, false, 0};
     int64_t run = 0;
-    for (uint32_t base = 0; base < maxsteps; base += 2048u) {
-        const uint32_t off = base + lane * 32u;
-        const uint32_t nst = off < maxsteps ? min(32u, maxsteps - off) : 0u;
-        uint32_t dl = 0, dh = 0, cg = 0, nn = 0;
-        if (nst) {
-            // bit b of every mask <-> step off + b
-            int32_t pt = dir > 0 ? et + (int32_t)off : et - (int32_t)off - 32, pq = pt - d;
-            const Win32 tw = win32(T, pt), qw = win32(Q, pq);
-            dl = tw.lo ^ qw.lo; dh = tw.hi ^ qw.hi; cg = tw.lo ^ tw.hi;
-            nn = tw.nm | qw.nm;
-            if (dir < 0) { dl = __brev(dl); dh = __brev(dh); cg = __brev(cg); nn = __brev(nn); }
-        }
-        const uint32_t valid = nst == 32 ? 0xFFFFFFFFu : ((1u << nst) - 1u);
-        int32_t S = 0, M = INT32_MIN / 2, mn = INT32_MAX / 2, a = 0;
-        uint32_t posM = 0;
-        if (nst) {
-            if (((dl | dh | nn) & valid) == 0) {  // all matches: prefixes strictly increase
-                S = 91 * (int32_t)nst + 9 * __popc(cg & valid);
-                M = S; posM = nst; mn = (cg & 1u) ? 100 : 91; a = 0;
-            } else {
-                int32_t p = 0;
-                for (uint32_t b = 0; b < nst; b++) {
-                    p += sub_score((dl >> b) & 1u, (dh >> b) & 1u, (cg >> b) & 1u, (nn >> b) & 1u);
-                    if (p > M) { M = p; posM = b + 1; }
-                    mn = min(mn, p);
-                    a = min(a, p - M);
-                }
-                S = p;
+    // the first step covers 2048 bases with one word per lane (most walks end there), later steps
+    // take WALK_WORDS words per lane
+    uint32_t nw = 1;
+    for (uint32_t base = 0; base < maxsteps; base += 64u * 32u * nw, nw = WALK_WORDS) {
+        const uint32_t off = base + lane * 32u * nw;
+        uint32_t dl[WALK_WORDS], dh[WALK_WORDS], cg[WALK_WORDS], nn[WALK_WORDS], nst[WALK_WORDS];
+#pragma unroll
+        for (int j = 0; j < WALK_WORDS; j++) {
+            const uint32_t o = off + 32u * j;
+            nst[j] = ((uint32_t)j < nw && o < maxsteps) ? min(32u, maxsteps - o) : 0u;
+            dl[j] = dh[j] = cg[j] = nn[j] = 0;
+            if (nst[j]) {  // bit b of every mask <-> step o + b
+                int32_t pt = dir > 0 ? et + (int32_t)o : et - (int32_t)o - 32, pq = pt - d;
+                const Win32 tw = win32(T, pt), qw = win32(Q, pq);
+                dl[j] = tw.lo ^ qw.lo; dh[j] = tw.hi ^ qw.hi; cg[j] = tw.lo ^ tw.hi; nn[j] = tw.nm | qw.nm;
+                if (dir < 0) { dl[j] = __brev(dl[j]); dh[j] = __brev(dh[j]); cg[j] = __brev(cg[j]); nn[j] = __brev(nn[j]); }
             }
         }
-        // running score entering my word, best entering my word
+        // lane summary over its (up to) 128 steps
+        int32_t S = 0, M = INT32_MIN / 2, mn = INT32_MAX / 2, a = 0;
+        uint32_t posM = 0, ntot = 0;
+#pragma unroll
+        for (int j = 0; j < WALK_WORDS; j++) {
+            if (!nst[j]) continue;
+            const uint32_t valid = nst[j] == 32 ? 0xFFFFFFFFu : ((1u << nst[j]) - 1u);
+            int32_t wS, wM, wmn, wa = 0;
+            uint32_t wpos;
+            if (((dl[j] | dh[j] | nn[j]) & valid) == 0) {  // all matches: prefixes strictly increase
+                wS = 91 * (int32_t)nst[j] + 9 * __popc(cg[j] & valid);
+                wM = wS; wpos = nst[j]; wmn = (cg[j] & 1u) ? 100 : 91;
+            } else {
+                int32_t p = 0;
+                wM = INT32_MIN / 2; wmn = INT32_MAX / 2; wpos = 0;
+                for (uint32_t bb = 0; bb < nst[j]; bb++) {
+                    p += sub_score((dl[j] >> bb) & 1u, (dh[j] >> bb) & 1u, (cg[j] >> bb) & 1u, (nn[j] >> bb) & 1u);
+                    if (p > wM) { wM = p; wpos = bb + 1; }
+                    wmn = min(wmn, p);
+                    wa = min(wa, p - wM);
+                }
+                wS = p;
+            }
+            if (ntot == 0) { S = wS; M = wM; mn = wmn; a = wa; posM = wpos; }
+            else {  // compose (lane so far) then (word j)
+                a = min(a, min(S - M + wmn, wa));
+                mn = min(mn, S + wmn);
+                if (S + wM > M) { M = S + wM; posM = ntot + wpos; }
+                S += wS;
+            }
+            ntot += nst[j];
+        }
+        // running score entering my lane, best entering my lane
         int64_t incS = wave_incl_sum((int64_t)S, lane);
         int64_t run_in = run + incS - S;
-        int64_t cand = nst ? run_in + M : INT64_MIN;  // best reached inside my word
+        int64_t cand = ntot ? run_in + M : INT64_MIN;  // best reached inside my lane
         int64_t incB = wave_incl_max(cand, lane);
         int64_t prevB = __shfl_up(incB, 1);
         int64_t best_in = lane ? max(r.best, prevB) : r.best;
-        bool mb = nst && (a < -xdrop || run_in + mn < best_in - xdrop);
+        bool mb = ntot && (a < -xdrop || run_in + mn < best_in - xdrop);
         uint64_t bmask = __ballot(mb);
         uint32_t first = bmask ? (uint32_t)__builtin_ctzll(bmask) : 64u;
-        // accept every word before `first`: best = earliest word reaching the maximum
-        int64_t cm = wave_max((lane < first && nst) ? cand : INT64_MIN);
+        // accept every lane before `first`: best = earliest lane reaching the maximum
+        int64_t cm = wave_max((lane < first && ntot) ? cand : INT64_MIN);
         if (cm > r.best) {
-            uint64_t em = __ballot(lane < first && nst && cand == cm);
+            uint64_t em = __ballot(lane < first && ntot && cand == cm);
             uint32_t wl = (uint32_t)__builtin_ctzll(em);
             r.best = cm;
-            r.bsteps = base + wl * 32u + (uint32_t)__shfl((int)posM, (int)wl);
+            r.bsteps = base + wl * 32u * nw + (uint32_t)__shfl((int)posM, (int)wl);
         }
         if (first < 64u) {
-            // the walk ends inside word `first`: replay it exactly on that lane
+            // the walk ends inside lane `first`: replay its bases exactly
             int64_t lb = r.best;
             uint32_t lbs = r.bsteps;
             if (lane == first) {
                 int64_t p = run_in;
-                for (uint32_t b = 0; b < nst; b++) {
-                    p += sub_score((dl >> b) & 1u, (dh >> b) & 1u, (cg >> b) & 1u, (nn >> b) & 1u);
-                    if (p > lb) { lb = p; lbs = off + b + 1; }
-                    if (p < lb - xdrop) break;
+                bool stop = false;
+#pragma unroll
+                for (int j = 0; j < WALK_WORDS; j++) {
+                    for (uint32_t bb = 0; bb < nst[j] && !stop; bb++) {
+                        p += sub_score((dl[j] >> bb) & 1u, (dh[j] >> bb) & 1u, (cg[j] >> bb) & 1u, (nn[j] >> bb) & 1u);
+                        if (p > lb) { lb = p; lbs = off + 32u * j + bb + 1; }
+                        if (p < lb - xdrop) stop = true;
+                    }
                 }
             }
             r.best = __shfl(lb, (int)first);
