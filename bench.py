@@ -63,6 +63,18 @@ def cpu_baseline(names, seqs, self_pair, cross_pair):
                       'S*t_self + (S*S-S)*t_cross = %.0f s' % (self_pair + (times[0],) + cross_pair + (times[1], S * S, total_s))}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per seed-scan launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 correction, calibrated on k3_join_count; profiles/r01_pmc_seed_scan.json).  Only C2 was measured."""
+    if workload != 'c2':
+        return None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_seed_scan.json')) as f:
+            return json.load(f)['k3_join_fill']['corrected_bytes_per_launch_cross_unit']
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -137,7 +149,7 @@ def main():
                                    % (args.workload.upper(), total_bp // 1_000_000, nscaf, total_bp / nscaf / 1e6, seed),
                        'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': 'pairs-sharded x%d' % dist.world},
             'roofline': {'kernel': 'k3_join_fill (seed scan)', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': None,
+                         'frac': achieved / 8000.0, 'traffic': pmc_traffic(args.workload), 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_seed_scan.json)',
                          'kernel_bytes_per_launch': st['scan_bytes_kernel'] / launches,
                          'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3},
             'stage_ms_rank0': {k: round(st[k], 3) for k in ('ms_index', 'ms_scan', 'ms_scan_fill', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_total')},
