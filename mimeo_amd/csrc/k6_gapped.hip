@@ -44,10 +44,55 @@ struct DpJob {
 };
 
 __device__ __forceinline__ Cell cmax_left(const Cell &l, const Cell &r) { return r.s > l.s ? r : l; }  // ties -> left
-__device__ __forceinline__ Cell shfl_cell(const Cell &c, int src) {
-    Cell o;
-    o.s = __shfl(c.s, src); o.nm = __shfl(c.nm, src); o.nx = __shfl(c.nx, src);
+
+// Cross-lane movement with DPP (VALU latency) instead of ds_bpermute (LDS-crossbar latency): the DP
+// keeps rank == lane, so every scan / neighbour access is a fixed lane pattern.
+// gfx9 DPP controls: row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ Cell dpp_cell(const Cell &c) {
+    Cell o;  // lanes without a valid source keep the identity (NEG, 0, 0)
+    o.s = __builtin_amdgcn_update_dpp(NEG, c.s, CTRL, RMASK, 0xf, false);
+    o.nm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.nm, CTRL, RMASK, 0xf, false);
+    o.nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.nx, CTRL, RMASK, 0xf, false);
     return o;
+}
+// inclusive max-scan over the 64 lanes, ties to the lower lane
+__device__ __forceinline__ Cell wave_incl_maxscan(Cell v) {
+    v = cmax_left(dpp_cell<0x111, 0xf>(v), v);
+    v = cmax_left(dpp_cell<0x112, 0xf>(v), v);
+    v = cmax_left(dpp_cell<0x114, 0xf>(v), v);
+    v = cmax_left(dpp_cell<0x118, 0xf>(v), v);
+    v = cmax_left(dpp_cell<0x142, 0xa>(v), v);
+    v = cmax_left(dpp_cell<0x143, 0xc>(v), v);
+    return v;
+}
+struct Best4 {
+    int32_t s;
+    uint32_t j, nm, nx;
+};
+template <int CTRL, int RMASK>
+__device__ __forceinline__ Best4 dpp_best(const Best4 &c) {
+    Best4 o;
+    o.s = __builtin_amdgcn_update_dpp(NEG, c.s, CTRL, RMASK, 0xf, false);
+    o.j = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.j, CTRL, RMASK, 0xf, false);
+    o.nm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.nm, CTRL, RMASK, 0xf, false);
+    o.nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.nx, CTRL, RMASK, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ Best4 bmax_left(const Best4 &l, const Best4 &r) { return r.s > l.s ? r : l; }
+// row maximum with the smallest column on ties: columns grow with the lane, so "ties to the lower
+// lane" is "smallest column"; the total ends up in lane 63
+__device__ __forceinline__ Best4 wave_best(Best4 v) {
+    v = bmax_left(dpp_best<0x111, 0xf>(v), v);
+    v = bmax_left(dpp_best<0x112, 0xf>(v), v);
+    v = bmax_left(dpp_best<0x114, 0xf>(v), v);
+    v = bmax_left(dpp_best<0x118, 0xf>(v), v);
+    v = bmax_left(dpp_best<0x142, 0xa>(v), v);
+    v = bmax_left(dpp_best<0x143, 0xc>(v), v);
+    Best4 t;
+    t.s = __builtin_amdgcn_readlane(v.s, 63); t.j = (uint32_t)__builtin_amdgcn_readlane((int)v.j, 63);
+    t.nm = (uint32_t)__builtin_amdgcn_readlane((int)v.nm, 63); t.nx = (uint32_t)__builtin_amdgcn_readlane((int)v.nx, 63);
+    return t;
 }
 
 // WSTRIP query bits for columns jb .. jb+WSTRIP-1 (bit s <-> column jb+s); column j consumes query base
@@ -100,10 +145,11 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
             return best;
         }
     }
-    // ---- general row-by-row DP
+    // ---- general row-by-row DP.  Lane l owns columns wb + 16*l .. wb + 16*l + 15 (rank == lane); when
+    // the first live column crosses a strip boundary the whole state moves down by that many lanes.
     int32_t Cs[WSTRIP], Ds[WSTRIP];
     uint32_t Cm[WSTRIP], Cx[WSTRIP], Dm[WSTRIP], Dx[WSTRIP];
-    uint32_t wb = 0, r = lane, jb = lane * WSTRIP;
+    uint32_t wb = 0, jb = lane * WSTRIP;
     uint32_t qlo, qhi, qn;
     load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
     bool over = false;
@@ -122,10 +168,8 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
         const Base1 ab = base_at(T, pa);
         const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
-        // C of the column left of my strip (previous row): last slot of the previous lane in ring order
-        Cell p7{Cs[WSTRIP - 1], Cm[WSTRIP - 1], Cx[WSTRIP - 1]};
-        p7 = shfl_cell(p7, (int)((lane + 63u) & 63u));
-        if (r == 0) p7.s = NEG;
+        // C of the column left of my strip (previous row): last slot of the previous lane
+        const Cell p7 = dpp_cell<0x138, 0xf>(Cell{Cs[WSTRIP - 1], Cm[WSTRIP - 1], Cx[WSTRIP - 1]});
         // pass 1 (slots descending, in place): D(i,j) and H(i,j) = max(diagonal, D) overwrite the
         // previous row's D and C; slot s still sees the old C of slot s-1
 #pragma unroll
@@ -150,31 +194,23 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
             Cs[s] = hh.s; Cm[s] = hh.nm; Cx[s] = hh.nx;
         }
         // pass 2: insertion state = exclusive max-plus scan of u_k = H_k + (k - wb) * E along the
-        // row: lane aggregate, then one cross-lane scan in ring order
+        // row: lane aggregate, then one cross-lane scan
         Cell run{NEG, 0, 0};
 #pragma unroll
         for (int s = 0; s < WSTRIP; s++) {
-            Cell u{Cs[s] > NEGH ? Cs[s] + (int32_t)(r * WSTRIP + s) * E : NEG, Cm[s], Cx[s]};
+            Cell u{Cs[s] > NEGH ? Cs[s] + (int32_t)(lane * WSTRIP + s) * E : NEG, Cm[s], Cx[s]};
             run = cmax_left(run, u);
         }
-        Cell inc = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Cell l = shfl_cell(inc, (int)((lane + 64u - (uint32_t)o) & 63u));
-            if (r >= (uint32_t)o) inc = cmax_left(l, inc);
-        }
-        Cell acc = shfl_cell(inc, (int)((lane + 63u) & 63u));  // best u of every column left of my strip
-        if (r == 0) acc = Cell{NEG, 0, 0};
+        Cell acc = dpp_cell<0x138, 0xf>(wave_incl_maxscan(run));  // best u of every column left of my strip
         // pass 3: C = max(H, I), prune, row statistics
         uint32_t amask = 0;
-        int32_t bs = NEG;
-        uint32_t bj = 0xFFFFFFFFu, bm = 0, bx = 0;
+        Best4 rb{NEG, 0xFFFFFFFFu, 0, 0};
 #pragma unroll
         for (int s = 0; s < WSTRIP; s++) {
             Cell hh{Cs[s], Cm[s], Cx[s]};
             Cell I{NEG, acc.nm, acc.nx};
-            if (acc.s > NEGH) I.s = acc.s - O - (int32_t)(r * WSTRIP + s) * E;
-            Cell u{hh.s > NEGH ? hh.s + (int32_t)(r * WSTRIP + s) * E : NEG, hh.nm, hh.nx};
+            if (acc.s > NEGH) I.s = acc.s - O - (int32_t)(lane * WSTRIP + s) * E;
+            Cell u{hh.s > NEGH ? hh.s + (int32_t)(lane * WSTRIP + s) * E : NEG, hh.nm, hh.nx};
             acc = cmax_left(acc, u);
             Cell c = hh;  // H preferred over I on ties
             if (I.s > c.s) c = I;
@@ -183,37 +219,39 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
             if (!alive) Ds[s] = NEG;
             if (alive) {
                 amask |= 1u << s;
-                if (c.s > bs) { bs = c.s; bj = jb + s; bm = c.nm; bx = c.nx; }
+                if (c.s > rb.s) { rb.s = c.s; rb.j = jb + s; rb.nm = c.nm; rb.nx = c.nx; }
             }
         }
         const uint64_t ball = __ballot(amask != 0);
         if (!ball) break;
-        const uint32_t base = (wb >> WSHIFT) & 63u;
-        const uint64_t rot = base ? (ball >> base) | (ball << (64 - base)) : ball;
-        const uint32_t rf = (uint32_t)__builtin_ctzll(rot), rl = 63u - (uint32_t)__builtin_clzll(rot);
+        const uint32_t rf = (uint32_t)__builtin_ctzll(ball), rl = 63u - (uint32_t)__builtin_clzll(ball);
         if (rl == 63u) { best.overflow = 1; break; }
-        // best cell of the row: max score, then smallest column
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            int32_t os = __shfl_xor(bs, o);
-            uint32_t oj = __shfl_xor(bj, o), om = __shfl_xor(bm, o), ox = __shfl_xor(bx, o);
-            if (os > bs || (os == bs && oj < bj)) { bs = os; bj = oj; bm = om; bx = ox; }
+        // best cell of the row (only when some lane beats the best of the rows above)
+        if (__ballot(rb.s > best.score)) {
+            const Best4 t = wave_best(rb);
+            if (t.s > best.score) { best.score = t.s; best.i = i; best.j = t.j; best.nm = t.nm; best.nx = t.nx; }
         }
-        if (bs > best.score) { best.score = bs; best.i = i; best.j = bj; best.nm = bm; best.nx = bx; }
         // slide the window so that it starts at the strip holding the first live column
-        const uint32_t fmask = (uint32_t)__shfl((int)amask, (int)((rf + base) & 63u));
+        const uint32_t fmask = (uint32_t)__builtin_amdgcn_readlane((int)amask, (int)rf);
         const uint32_t plo = wb + rf * WSTRIP + (uint32_t)__builtin_ctz(fmask);
         const uint32_t nwb = plo & ~(uint32_t)(WSTRIP - 1);
         if (nwb != wb) {
+            const uint32_t shift = (nwb - wb) >> WSHIFT;  // == rf
             wb = nwb;
-            r = (lane - ((wb >> WSHIFT) & 63u)) & 63u;
-            const uint32_t njb = wb + r * WSTRIP;
-            if (njb != jb) {  // this lane's strip left the window on the left: it re-enters on the right
-                jb = njb;
-                load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+            jb = wb + lane * WSTRIP;
+            const int src = (int)((lane + shift) & 63u);
+            const bool fresh = lane + shift >= 64u;  // strip re-enters on the right with new columns
 #pragma unroll
-                for (int s = 0; s < WSTRIP; s++) { Cs[s] = NEG; Ds[s] = NEG; }
+            for (int s = 0; s < WSTRIP; s++) {
+                int32_t cs = __shfl(Cs[s], src), ds = __shfl(Ds[s], src);
+                Cm[s] = __shfl(Cm[s], src); Cx[s] = __shfl(Cx[s], src);
+                Dm[s] = __shfl(Dm[s], src); Dx[s] = __shfl(Dx[s], src);
+                Cs[s] = fresh ? NEG : cs;
+                Ds[s] = fresh ? NEG : ds;
             }
+            uint32_t a0 = __shfl(qlo, src), a1 = __shfl(qhi, src), a2 = __shfl(qn, src);
+            if (fresh) load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+            else { qlo = a0; qhi = a1; qn = a2; }
         }
     }
     return best;
