@@ -91,7 +91,8 @@ def main():
     dist = Dist().init()
     if dist.world != max(1, args.gpus) and dist.rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dist.world), file=sys.stderr)
-    engine.init(dist.local_rank)
+    # MIMEO_FORCE_DEVICE lets several ranks share one GPU (rehearsing the N>1 path on a 1-GPU box)
+    engine.init(int(os.environ.get('MIMEO_FORCE_DEVICE', dist.local_rank)))
     seed, total_bp, nscaf = WORKLOADS[args.workload]
     names, seqs = synth_genome(seed, total_bp, nscaf)
     A = engine.Genome(names, seqs)  # packed, device resident: outside the timed region

@@ -63,7 +63,7 @@ def load_genome(fasta, directory, what):
 def start(args):
     init_logging(args.loglevel)
     dist = Dist().init()
-    dev = args.device if args.device is not None else dist.local_rank
+    dev = args.device if args.device is not None else int(os.environ.get('MIMEO_FORCE_DEVICE', dist.local_rank))
     engine.init(dev)
     outdir = os.path.abspath(args.outdir) if args.outdir else os.getcwd()
     if dist.rank == 0 and not os.path.isdir(outdir):

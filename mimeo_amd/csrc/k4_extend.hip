@@ -62,6 +62,7 @@ __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandVie
 // hit, or the sequence end fall back to single bases.
 constexpr int GROUP_TAB = 4096;
 constexpr int QCAP = 128;  // per-wave staging capacity of the K4a output queues
+constexpr int FAST_THREADS = 512;  // K4a fast kernel: 8 wavefronts share one copy of the group table
 
 static inline int host_sub(int dl, int dh, int cg) {
     static const int lo[4] = {91, 100, -31, -31}, hi[4] = {-114, -114, -123, -125};
@@ -219,6 +220,7 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
         w.k = go ? w.k + 4 : w.k;
         w.done = w.done || brk;
         act = go;
+        if ((c & 1) && c < 7 && !__ballot(act)) break;  // every lane of the wavefront has stopped
     }
     if (__ballot(slow)) {
         if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, slow_pos);
@@ -267,7 +269,7 @@ __device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, co
 }
 
 template <int VARIANT>  // 1 = production; 2 = loads only, 3 = compute only (timing experiments, wrong results)
-__global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
+__global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
                                                               const uint2 *__restrict__ hits, uint64_t nhits,
                                                               int xdrop, int hspthresh, int transitions,
                                                               const uint32_t *__restrict__ group_tab,
@@ -278,17 +280,17 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_hits(StrandView T, Stra
     __shared__ uint32_t tab[GROUP_TAB];
     // per-wave staging of the three output queues: one global atomic per >= 64 records instead of
     // one per wavefront iteration (same-address atomics serialise at ~15 ns each)
-    __shared__ uint2 s_med[EXT_THREADS / 64][QCAP];
-    __shared__ uint64_t s_fk[EXT_THREADS / 64][QCAP];
-    __shared__ uint32_t s_fp[EXT_THREADS / 64][QCAP];
-    __shared__ Cand s_cd[EXT_THREADS / 64][QCAP];
-    for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
+    __shared__ uint2 s_med[FAST_THREADS / 64][QCAP];
+    __shared__ uint64_t s_fk[FAST_THREADS / 64][QCAP];
+    __shared__ uint32_t s_fp[FAST_THREADS / 64][QCAP];
+    __shared__ Cand s_cd[FAST_THREADS / 64][QCAP];
+    for (int i = threadIdx.x; i < GROUP_TAB; i += FAST_THREADS) tab[i] = group_tab[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t n_med = 0, n_fol = 0, n_cd = 0;  // wave-uniform fill levels
-    const uint64_t stride = (uint64_t)gridDim.x * EXT_THREADS;
-    for (uint64_t g0 = (uint64_t)blockIdx.x * EXT_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * FAST_THREADS;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * FAST_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
         const uint64_t gid = g0 + lane;
         bool q_med = false, q_fol = false, q_cd = false;
         uint2 h = make_uint2(0, 0);
@@ -754,14 +756,14 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
         if ((rc = W.longq.reserve(nhits * 8))) return rc;
         if ((rc = W.medq.reserve(nhits * 8))) return rc;
         HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
-        uint64_t nb = (nhits + EXT_THREADS - 1) / EXT_THREADS;
-        if (nb > 256 * 32) nb = 256 * 32;  // grid-stride: the LDS table is loaded once per workgroup
+        uint64_t nb = (nhits + FAST_THREADS - 1) / FAST_THREADS;
+        if (nb > 256 * 16) nb = 256 * 16;  // grid-stride: the LDS table is loaded once per workgroup
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
-#define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
+#define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
                            p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p)
         if (variant == 0)
-            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)nb), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
+            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
                                p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
                                (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
         else if (variant == 2) K4_LAUNCH(2);

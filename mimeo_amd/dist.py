@@ -24,7 +24,7 @@ class Dist:
         import torch.distributed as td
         self._torch = torch
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('MIMEO_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         self.backend = backend
         if not td.is_initialized():
             if backend == 'nccl':

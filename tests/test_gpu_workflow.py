@@ -121,3 +121,26 @@ def test_cli_self_end_to_end(eng, tmp_path):
     exp_tab = _oracle_tab(names, seqs, names, seqs, [(a, b) for a in range(2) for b in range(2)], 100, 80)
     assert (out / 'mimeo_alignment.tab').read_text() == '\n'.join(exp_tab) + '\n'
     assert (out / 'mimeo-self_repeats.gff3').read_text().startswith('##gff-version 3\n#seqid\tsource')
+
+
+def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
+    """The N>1 path end to end: two ranks (gloo, sharing GPU 0) must report the same alignments and
+    regions as one rank.  On the 8-GPU node the same code runs over RCCL with one GPU per rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, 'bench.py', '--workload', 'small', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().split('\n')[-1])
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MIMEO_DIST_BACKEND='gloo', MIMEO_FORCE_DEVICE='0')
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), 'bench.py', '--gpus', '2', '--workload', 'small', '--steps', '1', '--warmup', '0'],
+                         cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = json.loads([l for l in two.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert b['n_gpus'] == 2 and b['result'] == a['result'] and b['scaling'] == 'strong'
+    assert b['config']['pair_strands_rank0'] < a['config']['pair_strands_rank0']
