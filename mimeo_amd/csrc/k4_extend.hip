@@ -32,7 +32,7 @@ constexpr int EXT_THREADS = 256;
 constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per direction
 
 struct ExtCounters {
-    unsigned long long ncand, nfollow, nlong, nhsp, nmed;
+    unsigned long long ncand, nfollow, nlong, nhsp, nmed, nbig;
 };
 
 struct Cand {
@@ -639,16 +639,84 @@ __global__ void k4_segment_flags(const uint64_t *__restrict__ key, const uint32_
     flag[i] = start ? 1 : 0;
 }
 
+// per-lane walk without seed detection, windows loaded on demand; false = still alive after
+// LONG_WINDOWS windows (the caller hands the work to a wavefront)
+__device__ __forceinline__ bool lane_walk(const uint32_t *__restrict__ tab, const StrandView &T, const StrandView &Q,
+                                          int32_t et, int32_t d, int dir, uint32_t limit, int xdrop, WalkState &w) {
+    for (int win = 0; !w.done; win++) {
+        if (win == LONG_WINDOWS) return false;
+        const int32_t P = dir < 0 ? et - 32 * (win + 1) : et + 32 * win, Pq = P - d;
+        const Win32 tw = win32(T, P), qw = win32(Q, Pq);
+        uint32_t mdl = tw.lo ^ qw.lo, mdh = tw.hi ^ qw.hi, mcg = tw.lo ^ tw.hi, mnn = tw.nm | qw.nm;
+        if (dir < 0) { mdl = __brev(mdl); mdh = __brev(mdh); mcg = __brev(mcg); mnn = __brev(mnn); }
+        walk_window(tab, w, mdl, mdh, mcg, mnn, 0u, limit, xdrop);
+    }
+    return true;
+}
+
+// One LANE per segment: almost every segment is a pair of neighbouring random hits (one head, one
+// follower, walks of a few dozen bases).  Segments with more than SMALL_SEG members or with a walk
+// longer than LONG_WINDOWS windows are queued for k4_resolve_segments (one wavefront each).
+constexpr uint32_t SMALL_SEG = 8;
+__global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(StrandView T, StrandView Q,
+                                                                const uint64_t *__restrict__ key,
+                                                                const uint32_t *__restrict__ prev, uint64_t nfollow,
+                                                                const uint64_t *__restrict__ seg_start, uint64_t nseg,
+                                                                int xdrop, int hspthresh,
+                                                                const uint32_t *__restrict__ group_tab,
+                                                                ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
+                                                                uint64_t cand_cap, uint64_t *__restrict__ bigseg) {
+    __shared__ uint32_t tab[GROUP_TAB];
+    for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
+    __syncthreads();
+    const uint64_t sid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
+    if (sid >= nseg) return;
+    const uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
+    bool big = end - beg > SMALL_SEG;
+    Cand out[SMALL_SEG];
+    uint32_t nout = 0;
+    if (!big) {
+        const int32_t d = (int32_t)(uint32_t)(key[beg] >> 32) - (int32_t)Q.len;
+        const int32_t het = (int32_t)prev[beg];
+        WalkState H{0, 0, 0, 0, false, false, 0};
+        big = !lane_walk(tab, T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop, H);
+        uint32_t reach = (uint32_t)het + H.bk;
+        for (uint64_t i = beg; i < end && !big; i++) {
+            const uint32_t et = (uint32_t)key[i];
+            if (et <= reach) continue;  // inside the region the previous extension reached
+            const int32_t eq = (int32_t)et - d;
+            WalkState L{0, 0, 0, 0, false, false, 0}, R{0, 0, 0, 0, false, false, 0};
+            if (!lane_walk(tab, T, Q, (int32_t)et, d, -1, (uint32_t)min((int32_t)et, eq), xdrop, L) ||
+                !lane_walk(tab, T, Q, (int32_t)et, d, +1, min(T.len - et, Q.len - (uint32_t)eq), xdrop, R)) {
+                big = true;
+                break;
+            }
+            if (L.best + R.best >= hspthresh) out[nout++] = Cand{et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best};
+            reach = et + R.bk;
+        }
+    }
+    if (big) {  // nothing has been emitted for this segment yet: the wavefront kernel redoes it
+        bigseg[atomicAdd(&ctr->nbig, 1ull)] = sid;
+        return;
+    }
+    for (uint32_t k = 0; k < nout; k++) {
+        unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
+        if (i < cand_cap) cand[i] = out[k];
+    }
+}
+
 // one wavefront per segment: replay "skip while seed end <= reach, else extend" (lastz diagEnd rule)
 __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T, StrandView Q,
                                                                    const uint64_t *__restrict__ key,
                                                                    const uint32_t *__restrict__ prev, uint64_t nfollow,
                                                                    const uint64_t *__restrict__ seg_start,
-                                                                   uint64_t nseg, int xdrop, int hspthresh,
+                                                                   uint64_t nseg, const uint64_t *__restrict__ list,
+                                                                   uint64_t nlist, int xdrop, int hspthresh,
                                                                    int transitions, ExtCounters *__restrict__ ctr,
                                                                    Cand *__restrict__ cand, uint64_t cand_cap) {
-    uint64_t sid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
-    if (sid >= nseg) return;
+    uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
+    if (wid >= nlist) return;
+    const uint64_t sid = list[wid];
     uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
     uint64_t k0 = key[beg];
     const int32_t d = (int32_t)(uint32_t)(k0 >> 32) - (int32_t)Q.len;
@@ -724,7 +792,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
 struct ExtWork {
     ExtCounters *ctr = nullptr;  // device
     uint32_t *group_tab = nullptr;  // device copy of the 4-base group table
-    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel;
+    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel, bigseg;
 };
 static ExtWork W;
 
@@ -813,11 +881,22 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
             HIP_TRY(hipMemcpyAsync(&nseg, W.nsel.p, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (nseg) {
-                uint64_t nbs = (nseg * 64 + EXT_THREADS - 1) / EXT_THREADS;
-                hipLaunchKernelGGL(k4_resolve_segments, dim3((uint32_t)nbs), dim3(EXT_THREADS), 0, st, T, Q,
-                                   (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
-                                   (const uint64_t *)W.segs.p, nseg, p->xdrop, p->hspthresh, p->transitions, W.ctr,
-                                   (Cand *)W.cand.p, cand_cap);
+                if ((rc = W.bigseg.reserve(nseg * 8))) return rc;
+                hipLaunchKernelGGL(k4_resolve_small, dim3((uint32_t)((nseg + EXT_THREADS - 1) / EXT_THREADS)),
+                                   dim3(EXT_THREADS), 0, st, T, Q, (const uint64_t *)W.fkey2.p,
+                                   (const uint32_t *)W.fprev2.p, nf, (const uint64_t *)W.segs.p, nseg, p->xdrop,
+                                   p->hspthresh, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
+                                   (uint64_t *)W.bigseg.p);
+                HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.nbig) {
+                    uint64_t nbs = (c.nbig * 64 + EXT_THREADS - 1) / EXT_THREADS;
+                    hipLaunchKernelGGL(k4_resolve_segments, dim3((uint32_t)nbs), dim3(EXT_THREADS), 0, st, T, Q,
+                                       (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
+                                       (const uint64_t *)W.segs.p, nseg, (const uint64_t *)W.bigseg.p,
+                                       (uint64_t)c.nbig, p->xdrop, p->hspthresh, p->transitions, W.ctr,
+                                       (Cand *)W.cand.p, cand_cap);
+                }
             }
             HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
