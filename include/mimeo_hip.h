@@ -180,7 +180,7 @@ int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, 
 /*
  * lastz --gfextend --entropy --hspthresh (A8): seed hits -> gap-free HSPs with the
  * per-diagonal "already extended" suppression.  Returned sorted by
- * (tstart-qstart, tstart).
+ * (tstart-qstart, tstart, length).
  */
 int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid,
                         uint32_t qstrand, const mimeo_params *p, mimeo_hsp **out, uint64_t *nout);

@@ -210,7 +210,8 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
         std::sort(h, h + nh, [](const mimeo_hsp &a, const mimeo_hsp &b) {
             int64_t da = (int64_t)a.tstart - a.qstart, db = (int64_t)b.tstart - b.qstart;
             if (da != db) return da < db;
-            return a.tstart < b.tstart;
+            if (a.tstart != b.tstart) return a.tstart < b.tstart;
+            return a.length < b.length;
         });
     } while (0);
     hits.release(); hsps.release(); it.release(); iq.release();

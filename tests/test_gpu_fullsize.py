@@ -1,0 +1,92 @@
+"""BASELINE-sized units (C2 scaffolds: 5 Mbp x 5 Mbp) checked through size-independent properties,
+because the CPU oracle needs minutes at this size: symmetry of the seed relation, validity of a
+sample of hits against a numpy restatement of the seed rule, HSP scores recomputed on the host,
+run-to-run determinism, and self-consistency of the full alignment stage."""
+import numpy as np
+import pytest
+
+from mimeo_amd.synth import synth_genome
+
+pytestmark = pytest.mark.gpu
+
+CARE = np.array([0, 1, 2, 4, 7, 8, 11, 13, 15, 16, 17, 18])
+HOX = np.array([[91, -114, -31, -123], [-114, 100, -125, -31], [-31, -125, 100, -114], [-123, -31, -114, 91]])
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from mimeo_amd import engine
+    engine.init(0)
+    names, seqs = synth_genome(50, 10_000_000, 2, repeat_frac=0.05)
+    g = engine.Genome(names, seqs)
+    code = [np.searchsorted(np.frombuffer(b'ACGT', np.uint8), s).astype(np.int8) for s in seqs]
+    yield engine, g, seqs, code
+    g.close()
+
+
+def _key(h):
+    return np.sort(h['tpos'].astype(np.uint64) << np.uint64(32) | h['qpos'].astype(np.uint64))
+
+
+def test_seed_relation_is_symmetric_and_valid(setup):
+    eng, g, seqs, code = setup
+    ab = eng.seed_hits(g, 0, g, 1, 0)
+    st = eng.stats()
+    assert st['seed_hits'] == ab.size and ab.size > 15_000_000
+    ba = eng.seed_hits(g, 1, g, 0, 0)
+    swapped = ba['qpos'].astype(np.uint64) << np.uint64(32) | ba['tpos'].astype(np.uint64)
+    assert np.array_equal(_key(ab), np.sort(swapped))
+    # every sampled hit obeys the 12of19 + one-transition rule
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, ab.size, 20000)
+    t = code[0][ab['tpos'][idx][:, None] + CARE[None, :]]
+    q = code[1][ab['qpos'][idx][:, None] + CARE[None, :]]
+    diff = t != q
+    assert (diff.sum(1) <= 1).all()
+    assert ((t ^ q)[diff] == 2).all()  # A<->G / C<->T flip only the high bit of the 2-bit code
+    # and the expected number of random hits: 13 * Lt * Lq / 4^12, plus the planted repeats
+    assert ab.size > 13 * 5e6 * 5e6 / 4 ** 12
+
+
+def test_hsps_deterministic_and_scores_recompute(setup):
+    eng, g, seqs, code = setup
+    p = eng.default_params(chain=0, entropy=0)
+    h1 = eng.ungapped_hsps(g, 0, g, 1, 0, p)
+    h2 = eng.ungapped_hsps(g, 0, g, 1, 0, p)
+    assert h1.size > 100 and h1.size == h2.size
+    cols = ['tstart', 'qstart', 'length', 'score', 'raw_score']
+    assert np.array_equal(np.sort(h1[cols], order=cols), np.sort(h2[cols], order=cols))  # same set
+    assert np.array_equal(h1, h2)  # and the documented order is total
+    rng = np.random.default_rng(2)
+    for k in rng.integers(0, h1.size, 300):
+        h = h1[k]
+        a = code[0][h['tstart']:h['tstart'] + h['length']]
+        b = code[1][h['qstart']:h['qstart'] + h['length']]
+        sc = HOX[a, b]
+        assert int(sc.sum()) == int(h['raw_score']) >= 3000
+        assert sc[0] > 0  # the left walk ends on a strict maximum, i.e. on a matching column
+
+
+def test_minus_strand_equals_plus_strand_of_reverse_complement(setup):
+    eng, g, seqs, code = setup
+    comp = np.frombuffer(b'TGCA', np.uint8)[code[1]][::-1].copy()
+    g2 = eng.Genome(['t', 'qrc'], [seqs[0], comp])
+    a = eng.ungapped_hsps(g, 0, g, 1, 1, eng.default_params(chain=0))
+    b = eng.ungapped_hsps(g2, 0, g2, 1, 0, eng.default_params(chain=0))
+    assert a.size > 50 and np.array_equal(a, b)
+    g2.close()
+
+
+def test_full_alignment_stage_self_consistency(setup):
+    eng, g, seqs, code = setup
+    al = eng.align_pairs(g, None, [(0, 1), (1, 0), (0, 0)])
+    st = eng.stats()
+    assert st['pair_strands'] == 6 and st['alignments'] == al.size
+    assert (al['score'] >= 3000).all() and (al['id_n'] <= al['id_d']).all()
+    assert (al['tend'] - al['tstart'] >= al['id_d'] // 2).all()
+    triv = al[(al['tid'] == 0) & (al['qid'] == 0) & (al['qstrand'] == 0)]
+    assert triv.size == 1 and triv['tstart'][0] == 0 and triv['tend'][0] == 5_000_000 and triv['id_n'][0] == 5_000_000
+    # the planted repeats are found in both directions: (0,1) and (1,0) see mirror images
+    ab = al[(al['tid'] == 0) & (al['qid'] == 1)]
+    ba = al[(al['tid'] == 1) & (al['qid'] == 0)]
+    assert ab.size > 10 and abs(int(ab.size) - int(ba.size)) <= max(3, ab.size // 10)
