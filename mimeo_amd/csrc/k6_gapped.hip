@@ -24,11 +24,7 @@ namespace mimeo {
 
 constexpr int32_t NEG = -(1 << 30);
 constexpr int32_t NEGH = -(1 << 29);
-constexpr int WSTRIP = 16;          // columns per lane
-constexpr int WINDOW = 64 * WSTRIP;  // columns in the sliding window
-constexpr uint32_t SMASK = (1u << WSTRIP) - 1u;
-constexpr int WSHIFT = 4;            // log2(WSTRIP)
-static_assert((1 << WSHIFT) == WSTRIP, "WSTRIP must be a power of two");
+// columns per lane: 16 (1024-column window) in k6_dp, 32 (2048 columns) in the second-chance kernel
 
 struct Cell {
     int32_t s;
@@ -97,8 +93,10 @@ __device__ __forceinline__ Best4 wave_best(Best4 v) {
 
 // WSTRIP query bits for columns jb .. jb+WSTRIP-1 (bit s <-> column jb+s); column j consumes query base
 // aq + j - 1 (dir > 0) or aq - j (dir < 0).  Out-of-range columns read padding and are never used.
+template <int WSTRIP>
 __device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int dir, uint32_t jb, uint32_t lenB,
                                            uint32_t &qlo, uint32_t &qhi, uint32_t &qn) {
+    constexpr uint32_t SMASK = WSTRIP == 32 ? 0xFFFFFFFFu : ((1u << (WSTRIP & 31)) - 1u);
     if (jb > lenB) { qlo = qhi = qn = 0; return; }
     if (dir > 0) {
         int32_t p = (int32_t)(aq + jb) - 1;
@@ -114,8 +112,12 @@ __device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int
 }
 
 // One-sided y-drop affine extension by one wavefront (all lanes return the same result).
+template <int WSTRIP>
 __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq, int dir,
                                        int32_t O, int32_t E, int32_t Y) {
+    constexpr int WINDOW = 64 * WSTRIP;  // columns in the sliding window
+    constexpr int WSHIFT = WSTRIP == 32 ? 5 : 4;
+    static_assert((1 << WSHIFT) == WSTRIP, "WSTRIP must be 16 or 32");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
     HalfResult best{0, 0, 0, 0, 0, 0};
@@ -151,7 +153,7 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
     uint32_t Cm[WSTRIP], Cx[WSTRIP], Dm[WSTRIP], Dx[WSTRIP];
     uint32_t wb = 0, jb = lane * WSTRIP;
     uint32_t qlo, qhi, qn;
-    load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+    load_qbits<WSTRIP>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
     bool over = false;
 #pragma unroll
     for (int s = 0; s < WSTRIP; s++) {
@@ -250,7 +252,7 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
                 Ds[s] = fresh ? NEG : ds;
             }
             uint32_t a0 = __shfl(qlo, src), a1 = __shfl(qhi, src), a2 = __shfl(qn, src);
-            if (fresh) load_qbits(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+            if (fresh) load_qbits<WSTRIP>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
             else { qlo = a0; qhi = a1; qn = a2; }
         }
     }
@@ -366,7 +368,17 @@ __global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, co
                                             HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
     const DpJob job = jobs[blockIdx.x];
     const Group &G = groups[job.group];
-    HalfResult r = wave_half_extend(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    HalfResult r = wave_half_extend<16>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
+}
+
+// second chance for half extensions whose band outgrew the 1024-column window: 2048 columns
+__global__ __launch_bounds__(64) void k6_dp_wide(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
+                                                 HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+    if (!res[blockIdx.x].overflow) return;
+    const DpJob job = jobs[blockIdx.x];
+    const Group &G = groups[job.group];
+    HalfResult r = wave_half_extend<32>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
     if (threadIdx.x == 0) res[blockIdx.x] = r;
 }
 
@@ -485,9 +497,12 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
             unsigned int h[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (h[0])
+            if (h[0]) {
                 hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
                                    (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+                hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
+                                   (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+            }
             hipLaunchKernelGGL(k6_resolve, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
                                (const HalfResult *)g_res.p, d_aln, remaining);
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 8, hipMemcpyDeviceToHost, st));

@@ -93,7 +93,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             for (size_t gi = 0; gi < groups.size(); gi++) {
                 const Group &g = groups[gi];
                 if (g.overflow) {
-                    set_error("gapped extension: DP band wider than the 1024-column register window, or score beyond int32: not supported yet");
+                    set_error("gapped extension: DP band wider than 2048 columns, or score beyond int32: not supported yet");
                     return MIMEO_ERR_LIMIT;
                 }
                 g_stats.chained_hsps += g.nchain;

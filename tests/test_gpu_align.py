@@ -103,3 +103,18 @@ def test_align_with_n_and_lowercase(eng):
     exp = O.align_pair(T.tobytes(), Q.tobytes())
     _cmp(got, exp, 'masked', ordered=True)
     g.close()
+
+
+def test_wide_band_second_chance_and_limit(eng):
+    """A large y-drop widens the DP band past the 1024-column register window: the 2048-column kernel
+    must take over with identical results; past 2048 columns the call fails loudly (no truncation)."""
+    from oracle import oracle as O
+    names, seqs = synth_genome(97, 120_000, 2, repeat_frac=0.2, families=2, cons_len=(800, 2000), max_div=0.1)
+    g = eng.Genome(names, seqs)
+    got = eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=25000))
+    exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes(), O.default_params(ydrop=25000))
+    assert exp.size > 2
+    _cmp(got, exp, 'wide', ordered=True)
+    with pytest.raises(RuntimeError, match='band'):
+        eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=90000))
+    g.close()
