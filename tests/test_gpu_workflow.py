@@ -144,3 +144,32 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     b = json.loads([l for l in two.stdout.strip().split('\n') if l.startswith('{')][-1])
     assert b['n_gpus'] == 2 and b['result'] == a['result'] and b['scaling'] == 'strong'
     assert b['config']['pair_strands_rank0'] < a['config']['pair_strands_rank0']
+
+
+def test_lastz_shim_runs_the_reference_invocation(eng, tmp_path):
+    """The literal argv the reference builds for lastz (wrappers.py:1025-1037) -> 13-field general
+    rows that the reference's own awk filter turns into the same TAB block as the oracle."""
+    import subprocess
+    import sys
+    from mimeo_amd.synth import write_fasta
+    from oracle import oracle as O, pipeline as P
+    names, seqs = synth_genome(54, 160_000, 2, repeat_frac=0.2, families=2, cons_len=(300, 1200))
+    ta, qa = str(tmp_path / 'scaf0000.fa'), str(tmp_path / 'scaf0001.fa')
+    write_fasta(ta, names[:1], seqs[:1])
+    write_fasta(qa, names[1:], seqs[1:])
+    out = str(tmp_path / 'temp_q_onto_t_.tab')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = [ta, qa, '--entropy', '--format=general:name1,strand1,start1,end1,length1,name2,strand2,start2+,end2+,length2,score,identity',
+            '--markend', '--gfextend', '--chain', '--gapped', '--step=1', '--strand=both', '--hspthresh=3000',
+            '--output=' + out, '--verbosity=0']
+    r = subprocess.run([sys.executable, '-m', 'mimeo_amd.lastz_shim'] + argv, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(out).read()
+    assert text.endswith('# lastz end-of-file\n')
+    al = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes())
+    al['tid'], al['qid'] = 0, 0
+    exp = P.general_rows(names[:1], names[1:], [len(seqs[1])], al)
+    assert [l for l in text.split('\n') if l and not l.startswith('#')] == exp
+    assert P.filter_project_sort(text, 100, 80) == P.filter_project_sort('\n'.join(exp), 100, 80)
+    bad = subprocess.run([sys.executable, '-m', 'mimeo_amd.lastz_shim', ta, qa, '--seed=match12'], cwd=root, capture_output=True, text=True)
+    assert bad.returncode != 0
