@@ -23,7 +23,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     g_err = buf;
     return MIMEO_ERR_HIP;
 }
-hipStream_t stream() { return g_stream; }
+// a worker thread of the library may run its launches on a stream of its own
+static thread_local hipStream_t tls_stream = nullptr;
+hipStream_t stream() { return tls_stream ? tls_stream : g_stream; }
+void set_thread_stream(hipStream_t s) { tls_stream = s; }
+int device_id() { return g_device; }
+std::string last_error_copy() { return g_err; }
 bool initialised() { return g_init; }
 
 static int need_init() {

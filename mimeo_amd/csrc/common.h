@@ -89,6 +89,9 @@ namespace mimeo {
 
 // stream used by every kernel launch of the library (created by mimeo_init)
 hipStream_t stream();
+void set_thread_stream(hipStream_t s);  // per-thread override (worker threads)
+int device_id();
+std::string last_error_copy();
 bool initialised();
 
 // K1: ASCII -> planes for both strands (k1_pack.hip)

@@ -18,6 +18,11 @@
 //   * jobs of different anchors are independent, only the skip rule is ordered: each round takes
 //     the next <= nbatch unskipped anchors of every group (k6_pick), extends them all (k6_dp),
 //     then replays the skip rule in order over the batch (k6_resolve).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "device_util.h"
 
 namespace mimeo {
@@ -33,6 +38,7 @@ struct Cell {
 struct HalfResult {
     int32_t score;
     uint32_t i, j, nm, nx, overflow;
+    uint32_t maxcols, rows;  // widest live band (columns from the window base) and rows evaluated: tuning statistics
 };
 struct DpJob {
     uint32_t group, at, aq;
@@ -120,7 +126,7 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
     static_assert((1 << WSHIFT) == WSTRIP, "WSTRIP must be 16 or 32");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
-    HalfResult best{0, 0, 0, 0, 0, 0};
+    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0};
     // ---- exact shortcut: identical, N-free to the end of the shorter sequence
     {
         const uint32_t n = min(lenA, lenB);
@@ -228,6 +234,8 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         if (!ball) break;
         const uint32_t rf = (uint32_t)__builtin_ctzll(ball), rl = 63u - (uint32_t)__builtin_clzll(ball);
         if (rl == 63u) { best.overflow = 1; break; }
+        best.maxcols = max(best.maxcols, (rl + 1u) * WSTRIP);
+        best.rows = i;
         // best cell of the row (only when some lane beats the best of the rows above)
         if (__ballot(rb.s > best.score)) {
             const Best4 t = wave_best(rb);
@@ -502,6 +510,22 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                                    (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
                 hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
                                    (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+            }
+            if (getenv("MIMEO_K6_STATS") && h[0]) {
+                std::vector<HalfResult> hr(h[0]);
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(hr.data(), g_res.p, (size_t)h[0] * sizeof(HalfResult), hipMemcpyDeviceToHost));
+                unsigned long long hist[9] = {0}, rows = 0, maxr = 0, shortcut = 0;
+                for (auto &r : hr) {
+                    if (!r.rows) { shortcut++; continue; }
+                    hist[std::min<uint32_t>(8, r.maxcols / 128)]++; rows += r.rows; maxr = std::max<unsigned long long>(maxr, r.rows);
+                }
+                fprintf(stderr, "[k6] jobs %u shortcut %llu rows total %llu max %llu band<128..>=1024:", h[0], shortcut, rows, maxr);
+                for (int b = 0; b < 9; b++) fprintf(stderr, " %llu", hist[b]);
+                fprintf(stderr, "\n");
+                int shown = 0;
+                for (auto &r : hr)
+                    if (!r.rows && shown < 8) { fprintf(stderr, "  [k6] zero-row job: score %d i %u j %u nm %u nx %u ovf %u\n", r.score, r.i, r.j, r.nm, r.nx, r.overflow); shown++; }
             }
             hipLaunchKernelGGL(k6_resolve, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
                                (const HalfResult *)g_res.p, d_aln, remaining);

@@ -8,8 +8,10 @@
 // workgroup per unit in K5, one wavefront per half extension in K6).
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <tuple>
 
@@ -53,7 +55,70 @@ static uint64_t scan_bytes_kernel(uint64_t nT, uint64_t nQ, uint64_t H) {
     return 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 4ull * (nT + nQ) + 8ull * H;
 }
 
-static DeviceBuf g_hits, g_unit_hsps, g_all_hsps, g_scratch, g_aln, g_groups;
+static DeviceBuf g_hits, g_unit_hsps, g_hsp_batch[2], g_scratch, g_aln, g_groups;
+static hipStream_t g_stream2 = nullptr;
+// MIMEO_OVERLAP=1 runs K5/K6 of a finished batch on a second stream while the next batch goes through
+// K3/K4.  Off by default: on C2 the two phases compete for the same VALUs (step 0.585 s vs 0.561 s
+// without overlap) and the co-running kernels distort the per-kernel timings.
+static bool g_overlap = false;
+
+// One batch of units whose HSPs are complete: K5 + K6 + read-back.  Runs on a worker thread with
+// its own stream so that the latency-bound K6 rounds of batch b overlap K3/K4 of batch b+1.
+struct Batch {
+    std::vector<Group> groups;
+    std::vector<uint64_t> group_pair;
+    uint64_t nh_total = 0;
+    int buf = 0;
+};
+struct BatchResult {
+    int rc = 0;
+    std::string err;
+    uint64_t chained = 0;
+    float ms_chain = 0, ms_gapped = 0;
+};
+
+static BatchResult run_batch(Batch b, const mimeo_params *p, std::vector<std::vector<mimeo_alignment>> *per_pair) {
+    BatchResult r;
+    (void)hipSetDevice(device_id());
+    struct StreamScope {  // the worker's launches go to the second stream; restored on every return path
+        StreamScope(hipStream_t s) { set_thread_stream(s); }
+        ~StreamScope() { set_thread_stream(nullptr); }
+    } scope(g_overlap ? g_stream2 : nullptr);
+    hipStream_t st = stream();
+    auto fail = [&](int rc) { r.rc = rc; r.err = last_error_copy(); return r; };
+    if (!b.nh_total || b.groups.empty()) return r;
+    int rc;
+    if ((rc = g_groups.reserve(b.groups.size() * sizeof(Group)))) return fail(rc);
+    if ((rc = g_aln.reserve(b.nh_total * sizeof(mimeo_alignment)))) return fail(rc);
+    if (hipMemcpyAsync(g_groups.p, b.groups.data(), b.groups.size() * sizeof(Group), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(MIMEO_ERR_HIP);
+    if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)b.groups.size(), (const mimeo_hsp *)g_hsp_batch[b.buf].p,
+                                  b.nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &r.ms_chain, &r.ms_gapped)))
+        return fail(rc);
+    std::vector<mimeo_alignment> host_aln(b.nh_total);
+    if (hipMemcpyAsync(b.groups.data(), g_groups.p, b.groups.size() * sizeof(Group), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(host_aln.data(), g_aln.p, b.nh_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        set_error("HIP error while reading back alignments");
+        return fail(MIMEO_ERR_HIP);
+    }
+    if (getenv("MIMEO_K6_STATS"))
+        for (size_t gi = 0; gi < b.groups.size() && gi < 24; gi++)
+            fprintf(stderr, "  [grp] t%u q%u %c hsps %llu nchain %u naln %u\n", b.groups[gi].tid, b.groups[gi].qid,
+                    b.groups[gi].minus ? '-' : '+', (unsigned long long)(b.groups[gi].hsp_end - b.groups[gi].hsp_begin),
+                    b.groups[gi].nchain, b.groups[gi].naln);
+    for (size_t gi = 0; gi < b.groups.size(); gi++) {
+        const Group &g = b.groups[gi];
+        if (g.overflow) {
+            set_error("gapped extension: DP band wider than 2048 columns, or score beyond int32: not supported yet");
+            return fail(MIMEO_ERR_LIMIT);
+        }
+        r.chained += g.nchain;
+        auto &dst = (*per_pair)[b.group_pair[gi]];
+        dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
+    }
+    return r;
+}
 
 int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
@@ -62,6 +127,8 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     const mimeo_genome *QG = B ? B : A;
     for (uint64_t k = 0; k < npairs; k++)
         if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
+    if (!g_stream2) HIP_TRY(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+    g_overlap = getenv("MIMEO_OVERLAP") && atoi(getenv("MIMEO_OVERLAP")) != 0;
     // stable grouping of pair indices by target
     std::vector<uint64_t> ord(npairs);
     for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
@@ -73,37 +140,35 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     hipStream_t st = stream();
     int rc = 0;
     uint64_t pos = 0;
-    // units (target, query, strand) accumulate into one batch of groups; K5/K6 run once per batch
-    std::vector<Group> groups;
-    std::vector<uint64_t> group_pair;
-    uint64_t nh_total = 0;
+    // units accumulate into a batch; a full batch is handed to the worker (K5/K6) while the next one
+    // is being filled.  Four batches per call (at most MAX_GROUPS units each).
+    uint64_t nunits = 0;
+    for (int m = 0; m < 2; m++) if (p->strand & (m ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS)) nunits += npairs;
     const size_t MAX_GROUPS = 8192;
+    const size_t batch_groups = g_overlap ? std::max<size_t>(8, std::min<size_t>(MAX_GROUPS, (nunits + 3) / 4)) : MAX_GROUPS;
+    Batch cur;
+    cur.buf = 0;
+    std::future<BatchResult> pending[2];
+    auto collect = [&](int buf) -> int {  // wait for the batch that used buffer `buf`
+        if (!pending[buf].valid()) return 0;
+        BatchResult r = pending[buf].get();
+        g_stats.chained_hsps += r.chained;
+        ms_chain += r.ms_chain;
+        ms_gapped += r.ms_gapped;
+        if (r.rc) { set_error(r.err); return r.rc; }
+        return 0;
+    };
     auto flush = [&]() -> int {
-        int frc = 0;
-        if (nh_total && !groups.empty()) {
-            if ((frc = g_groups.reserve(groups.size() * sizeof(Group)))) return frc;
-            if ((frc = g_aln.reserve(nh_total * sizeof(mimeo_alignment)))) return frc;
-            HIP_TRY(hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st));
-            if ((frc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_all_hsps.p,
-                                           nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain, &ms_gapped)))
-                return frc;
-            HIP_TRY(hipMemcpy(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost));
-            std::vector<mimeo_alignment> host_aln(nh_total);
-            HIP_TRY(hipMemcpy(host_aln.data(), g_aln.p, nh_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost));
-            for (size_t gi = 0; gi < groups.size(); gi++) {
-                const Group &g = groups[gi];
-                if (g.overflow) {
-                    set_error("gapped extension: DP band wider than 2048 columns, or score beyond int32: not supported yet");
-                    return MIMEO_ERR_LIMIT;
-                }
-                g_stats.chained_hsps += g.nchain;
-                auto &dst = per_pair[group_pair[gi]];
-                dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
-            }
-        }
-        groups.clear();
-        group_pair.clear();
-        nh_total = 0;
+        HIP_TRY(hipStreamSynchronize(st));  // the batch's HSP copies are complete
+        int buf = cur.buf;
+        // one worker at a time (they share the K5/K6 work buffers); this also frees the other HSP
+        // buffer, which is the one refilled next
+        int prc = collect(buf ^ 1);
+        if (prc) return prc;
+        pending[buf] = std::async(g_overlap ? std::launch::async : std::launch::deferred, run_batch, std::move(cur), p, &per_pair);
+        if (!g_overlap) { int r0 = collect(buf); if (r0) return r0; }
+        cur = Batch();
+        cur.buf = buf ^ 1;
         return 0;
     };
     while (pos < npairs && !rc) {
@@ -126,22 +191,23 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                 if ((rc = join_hits(ti, qi, p->transitions, g_hits, &nhits, &tm))) break;
                 if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)g_hits.p, nhits, p, g_unit_hsps, &nh, &ms_ext))) break;
                 // append this unit's HSPs to the batch-level array
-                if ((nh_total + nh) * sizeof(mimeo_hsp) > g_all_hsps.cap) {
+                DeviceBuf &hb = g_hsp_batch[cur.buf];
+                if ((cur.nh_total + nh) * sizeof(mimeo_hsp) > hb.cap) {
                     DeviceBuf bigger;
-                    if ((rc = bigger.reserve((nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) break;
-                    if (nh_total) HIP_TRY(hipMemcpyAsync(bigger.p, g_all_hsps.p, nh_total * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
+                    if ((rc = bigger.reserve((cur.nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) break;
+                    if (cur.nh_total) HIP_TRY(hipMemcpyAsync(bigger.p, hb.p, cur.nh_total * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
                     HIP_TRY(hipStreamSynchronize(st));
-                    g_all_hsps.release();
-                    g_all_hsps = bigger;
+                    hb.release();
+                    hb = bigger;
                 }
-                if (nh) HIP_TRY(hipMemcpyAsync((char *)g_all_hsps.p + nh_total * sizeof(mimeo_hsp), g_unit_hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
+                if (nh) HIP_TRY(hipMemcpyAsync((char *)hb.p + cur.nh_total * sizeof(mimeo_hsp), g_unit_hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
                 Group g;
                 memset(&g, 0, sizeof g);
                 g.T = tv; g.Q = qv; g.tid = tid; g.qid = qid; g.minus = (uint32_t)minus;
-                g.hsp_begin = nh_total; g.hsp_end = nh_total + nh;
-                groups.push_back(g);
-                group_pair.push_back(ord[k]);
-                nh_total += nh;
+                g.hsp_begin = cur.nh_total; g.hsp_end = cur.nh_total + nh;
+                cur.groups.push_back(g);
+                cur.group_pair.push_back(ord[k]);
+                cur.nh_total += nh;
                 g_stats.pair_strands++;
                 g_stats.seed_hits += nhits;
                 g_stats.hsps += nh;
@@ -149,12 +215,13 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                 g_stats.scan_bytes_algorithmic += scan_bytes_algorithmic(qs.len, nhits);
                 g_stats.scan_bytes_kernel += scan_bytes_kernel(ti.n, qi.n, nhits);
                 g_stats.scan_launches++;
-                if (groups.size() >= MAX_GROUPS) rc = flush();
+                if (cur.groups.size() >= batch_groups) rc = flush();
             }
         }
         pos = end;
     }
-    if (!rc) rc = flush();
+    if (!rc && !cur.groups.empty()) rc = flush();
+    for (int b = 0; b < 2; b++) { int r2 = collect(b); if (!rc) rc = r2; }
     cache.clear();
     if (rc) return rc;
     uint64_t total = 0;
