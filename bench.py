@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--emulate', default=None, help='R/N: time the shard rank R of N would get, on this one GPU, without communication (development aid)')
     args = ap.parse_args()
 
     from mimeo_amd import _ffi, engine, formats, workflow
@@ -98,7 +99,8 @@ def main():
     A = engine.Genome(names, seqs)  # packed, device resident: outside the timed region
     pairs = workflow.all_pairs(nscaf)
     L = A.lengths
-    mine = split_contiguous(pairs, lambda p: L[p[0]] * L[p[1]] * (3.0 if p[0] == p[1] else 1.0), dist.world, dist.rank)
+    ew, er = (int(args.emulate.split('/')[1]), int(args.emulate.split('/')[0])) if args.emulate else (dist.world, dist.rank)
+    mine = split_contiguous(pairs, lambda p: L[p[0]] * L[p[1]] * (3.0 if p[0] == p[1] else 1.0), ew, er)
     params = engine.default_params()
     names_sorted = sorted(names, key=lambda s: s.encode())
     cid = {n: i for i, n in enumerate(names_sorted)}

@@ -69,6 +69,7 @@ struct SeedIndex {
     uint32_t *off = nullptr;
     uint32_t *pos = nullptr;
     uint32_t n = 0;
+    size_t pos_bytes = 0;  // allocation size of pos (free-list key)
     IndexView view() const { return IndexView{off, pos, n}; }
     void release();
 };

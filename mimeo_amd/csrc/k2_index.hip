@@ -8,6 +8,8 @@
 // The (key,pos) ordering uses rocPRIM's device radix sort: this is plumbing executed 2*S times
 // per job against S^2*2 seed scans, not a hot kernel.
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -46,31 +48,54 @@ __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict
     }
 }
 
+// Device allocations are slow (tens to hundreds of microseconds each) and an index build used to do
+// a dozen of them: the temporaries live in a grow-only workspace, and released off/pos arrays go to
+// a small free list that the next build of the same size picks up.
+static DeviceBuf g_hist, g_keys_in, g_keys_out, g_pos_in, g_tmp;
+static std::vector<std::pair<size_t, void *>> g_free_list;
+
+static int pool_alloc(void **p, size_t bytes) {
+    for (size_t i = 0; i < g_free_list.size(); i++)
+        if (g_free_list[i].first == bytes) {
+            *p = g_free_list[i].second;
+            g_free_list.erase(g_free_list.begin() + i);
+            return 0;
+        }
+    HIP_TRY(hipMalloc(p, bytes));
+    return 0;
+}
+static void pool_free(void *p, size_t bytes) {
+    if (!p) return;
+    if (g_free_list.size() >= 512) { (void)hipFree(p); return; }
+    g_free_list.emplace_back(bytes, p);
+}
+
 void SeedIndex::release() {
-    if (off) (void)hipFree(off);
-    if (pos) (void)hipFree(pos);
+    pool_free(off, ((size_t)NBUCKET + 2) * 4);
+    pool_free(pos, pos_bytes);
     off = pos = nullptr;
     n = 0;
+    pos_bytes = 0;
 }
 
 int build_index(const StrandView &s, SeedIndex &out, float *ms) {
     out.release();
     uint32_t len = s.len;
     uint32_t nwords = (len + 31) / 32;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    static hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
     HIP_TRY(hipEventRecord(e0, stream()));
-    uint32_t *hist = nullptr;
-    HIP_TRY(hipMalloc((void **)&hist, ((size_t)NBUCKET + 2) * 4));
-    HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)NBUCKET + 2) * 4, stream()));
-    HIP_TRY(hipMalloc((void **)&out.off, ((size_t)NBUCKET + 2) * 4));
     size_t n = len ? len : 1;
-    uint32_t *keys_in = nullptr, *keys_out = nullptr, *pos_in = nullptr;
-    HIP_TRY(hipMalloc((void **)&keys_in, n * 4));
-    HIP_TRY(hipMalloc((void **)&keys_out, n * 4));
-    HIP_TRY(hipMalloc((void **)&pos_in, n * 4));
-    HIP_TRY(hipMalloc((void **)&out.pos, n * 4));
+    int rc;
+    if ((rc = g_hist.reserve(((size_t)NBUCKET + 2) * 4)) || (rc = g_keys_in.reserve(n * 4)) ||
+        (rc = g_keys_out.reserve(n * 4)) || (rc = g_pos_in.reserve(n * 4)))
+        return rc;
+    uint32_t *hist = (uint32_t *)g_hist.p, *keys_in = (uint32_t *)g_keys_in.p, *keys_out = (uint32_t *)g_keys_out.p,
+             *pos_in = (uint32_t *)g_pos_in.p;
+    HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)NBUCKET + 2) * 4, stream()));
+    if ((rc = pool_alloc((void **)&out.off, ((size_t)NBUCKET + 2) * 4))) return rc;
+    out.pos_bytes = n * 4;
+    if ((rc = pool_alloc((void **)&out.pos, out.pos_bytes))) return rc;
     if (nwords)
         hipLaunchKernelGGL(k2_seed_keys, dim3((nwords + 255) / 256), dim3(256), 0, stream(), s, nwords, keys_in,
                            pos_in, hist);
@@ -82,8 +107,8 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms) {
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp2, keys_in, keys_out, pos_in, out.pos, (size_t)len, 0, 25,
                                           stream()));
     if (tmp2 > tmp_bytes) tmp_bytes = tmp2;
-    void *tmp = nullptr;
-    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    if ((rc = g_tmp.reserve(tmp_bytes + 16))) return rc;
+    void *tmp = g_tmp.p;
     HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, hist, out.off, 0u, (size_t)NBUCKET + 1, rocprim::plus<uint32_t>(),
                                     stream()));
     if (len)
@@ -99,13 +124,6 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms) {
         HIP_TRY(hipEventElapsedTime(&t, e0, e1));
         *ms += t;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    HIP_TRY(hipFree(tmp));
-    HIP_TRY(hipFree(hist));
-    HIP_TRY(hipFree(keys_in));
-    HIP_TRY(hipFree(keys_out));
-    HIP_TRY(hipFree(pos_in));
     HIP_TRY(hipGetLastError());
     return 0;
 }
