@@ -102,7 +102,7 @@ __device__ __forceinline__ Best4 wave_best(Best4 v) {
 template <int WSTRIP>
 __device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int dir, uint32_t jb, uint32_t lenB,
                                            uint32_t &qlo, uint32_t &qhi, uint32_t &qn) {
-    constexpr uint32_t SMASK = WSTRIP == 32 ? 0xFFFFFFFFu : ((1u << (WSTRIP & 31)) - 1u);
+    constexpr uint32_t SMASK = WSTRIP == 32 ? 0xFFFFFFFFu : ((1u << (WSTRIP & 31)) - 1u);  // WSTRIP in {4, 16, 32}
     if (jb > lenB) { qlo = qhi = qn = 0; return; }
     if (dir > 0) {
         int32_t p = (int32_t)(aq + jb) - 1;
@@ -267,6 +267,206 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
     return best;
 }
 
+// ---- four-wavefront variant of the same DP -----------------------------------------------------
+// One workgroup of four wavefronts (one per SIMD) shares a half extension: wavefront of rank r owns
+// the 256 columns wb + 256 r ..., four per lane.  The row costs each wavefront a quarter of the
+// VALU work of the single-wavefront kernel plus two workgroup barriers, so a half extension finishes
+// ~3-4x sooner — which is what matters when a K6 round has fewer jobs than the chip has SIMDs
+// (multi-GPU shards, last rounds).  The window slides in whole 256-column blocks (the ring of four
+// wavefronts rotates, no state moves), so only 769 columns are guaranteed; a band that does not fit
+// is redone by the single-wavefront kernels.
+constexpr int C4_WS = 4, C4_WCOLS = 64 * C4_WS, C4_THREADS = 256;
+
+struct C4Shared {
+    Cell bnd[2][4];   // [row parity][wavefront]: C of the wavefront's last column
+    Cell tot[4];      // per-wavefront maximum of u
+    uint32_t first[4], last[4];
+    Best4 best[4];
+    int flag;
+};
+
+__device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq,
+                                        int dir, int32_t O, int32_t E, int32_t Y) {
+    constexpr int WS = C4_WS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
+    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- exact shortcut: identical, N-free to the end of the shorter sequence
+    {
+        const uint32_t n = min(lenA, lenB);
+        const int32_t st = dir > 0 ? (int32_t)at : (int32_t)(at - n), sq = dir > 0 ? (int32_t)aq : (int32_t)(aq - n);
+        bool ok = true;
+        uint32_t ncg = 0;
+        for (uint32_t k0 = 0; k0 < n; k0 += C4_THREADS * 32u) {
+            uint32_t k = k0 + tid * 32u;
+            if (k < n) {
+                const Win32 tw = win32(T, st + (int32_t)k), qw = win32(Q, sq + (int32_t)k);
+                uint32_t bad = (tw.lo ^ qw.lo) | (tw.hi ^ qw.hi) | tw.nm | qw.nm;
+                uint32_t rem = n - k, mask = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+                if (bad & mask) ok = false;
+                ncg += __popc((tw.lo ^ tw.hi) & mask);
+            }
+            if (__syncthreads_or(!ok)) { ok = false; break; }
+        }
+        if (!__syncthreads_or(!ok)) {
+            // block sum of ncg through the shared scratch (64-bit total)
+            unsigned long long tsum = ncg;
+            for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
+            if (lane == 0) { sh.first[wave] = (uint32_t)tsum; sh.last[wave] = (uint32_t)(tsum >> 32); }
+            __syncthreads();
+            unsigned long long all = 0;
+            for (int w = 0; w < 4; w++) all += ((unsigned long long)sh.last[w] << 32) | sh.first[w];
+            __syncthreads();
+            unsigned long long sc = 100ull * all + 91ull * ((unsigned long long)n - all);
+            best.score = (int32_t)sc; best.i = n; best.j = n; best.nm = n; best.nx = 0;
+            best.overflow = sc >= (1ull << 31) ? 1u : 0u;
+            return best;
+        }
+    }
+    // ---- row-by-row DP
+    int32_t Cs[WS], Ds[WS];
+    uint32_t Cm[WS], Cx[WS], Dm[WS], Dx[WS];
+    uint32_t wb = 0, wbase = 0;                      // window base column (multiple of 256), wavefront holding it
+    uint32_t rw = wave, jb = rw * C4_WCOLS + lane * WS;  // my rank in the ring, my first column
+    uint32_t qlo, qhi, qn;
+    load_qbits<WS>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+#pragma unroll
+    for (int s = 0; s < WS; s++) {
+        uint32_t j = jb + s;
+        int32_t v = j ? -O - (int32_t)j * E : 0;
+        bool alive = j <= lenB && (j == 0 || v >= -Y);
+        Cs[s] = alive ? v : NEG; Cm[s] = 0; Cx[s] = 0;
+        Ds[s] = NEG; Dm[s] = 0; Dx[s] = 0;
+    }
+    {   // row 0 must fit the guaranteed part of the window
+        uint32_t hi0 = 0;
+        if (Y >= O + E) hi0 = min(lenB, (uint32_t)((Y - O) / E));
+        if (hi0 >= 4 * C4_WCOLS - WS) { best.overflow = 1; return best; }
+    }
+    if (lane == 63) sh.bnd[0][wave] = Cell{Cs[WS - 1], 0, 0};
+    __syncthreads();
+    uint32_t par = 0;
+    for (uint32_t i = 1; i <= lenA; i++, par ^= 1u) {
+        const int32_t thr = best.score - Y;
+        const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
+        const Base1 ab = base_at(T, pa);
+        const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
+        // C of the column left of my strip (previous row)
+        Cell p7 = dpp_cell<0x138, 0xf>(Cell{Cs[WS - 1], Cm[WS - 1], Cx[WS - 1]});
+        if (lane == 0) p7 = rw ? sh.bnd[par][(wave + 3u) & 3u] : Cell{NEG, 0, 0};
+#pragma unroll
+        for (int s = WS - 1; s >= 0; s--) {
+            const uint32_t j = jb + s;
+            const bool exists = j <= lenB;
+            Cell dd{NEG, 0, 0}, g{NEG, 0, 0};
+            if (Ds[s] > NEGH) { dd.s = Ds[s] - E; dd.nm = Dm[s]; dd.nx = Dx[s]; }
+            if (Cs[s] > NEGH && Cs[s] - O - E > dd.s) { dd.s = Cs[s] - O - E; dd.nm = Cm[s]; dd.nx = Cx[s]; }
+            Cell pc = s ? Cell{Cs[s ? s - 1 : 0], Cm[s ? s - 1 : 0], Cx[s ? s - 1 : 0]} : p7;
+            if (pc.s > NEGH && j >= 1) {
+                uint32_t dl = alo ^ ((qlo >> s) & 1u), dh = ahi ^ ((qhi >> s) & 1u), nn = an | ((qn >> s) & 1u);
+                bool m = !(dl | dh | nn);
+                g.s = pc.s + sub_score(dl, dh, acg, nn);
+                g.nm = pc.nm + (m ? 1u : 0u);
+                g.nx = pc.nx + (m ? 0u : 1u);
+            }
+            if (!exists) { dd.s = NEG; g.s = NEG; }
+            Ds[s] = dd.s; Dm[s] = dd.nm; Dx[s] = dd.nx;
+            Cell hh = g;
+            if (dd.s > g.s) hh = dd;
+            Cs[s] = hh.s; Cm[s] = hh.nm; Cx[s] = hh.nx;
+        }
+        // insertion state: u_k = H_k + (k - wb) * E; in-lane, in-wavefront (DPP), across wavefronts (LDS)
+        const int32_t koff = (int32_t)(rw * C4_WCOLS + lane * WS);
+        Cell run{NEG, 0, 0};
+#pragma unroll
+        for (int s = 0; s < WS; s++) {
+            Cell u{Cs[s] > NEGH ? Cs[s] + (koff + s) * E : NEG, Cm[s], Cx[s]};
+            run = cmax_left(run, u);
+        }
+        const Cell inc = wave_incl_maxscan(run);
+        if (lane == 63) sh.tot[wave] = inc;
+        __syncthreads();
+        Cell acc{NEG, 0, 0};
+        for (uint32_t r = 0; r < rw; r++) acc = cmax_left(acc, sh.tot[(wbase + r) & 3u]);
+        acc = cmax_left(acc, dpp_cell<0x138, 0xf>(inc));
+        uint32_t amask = 0;
+        Best4 rb{NEG, 0xFFFFFFFFu, 0, 0};
+#pragma unroll
+        for (int s = 0; s < WS; s++) {
+            Cell hh{Cs[s], Cm[s], Cx[s]};
+            Cell I{NEG, acc.nm, acc.nx};
+            if (acc.s > NEGH) I.s = acc.s - O - (koff + s) * E;
+            Cell u{hh.s > NEGH ? hh.s + (koff + s) * E : NEG, hh.nm, hh.nx};
+            acc = cmax_left(acc, u);
+            Cell c = hh;
+            if (I.s > c.s) c = I;
+            const bool alive = (jb + s <= lenB) && c.s >= thr && c.s > NEGH;
+            Cs[s] = alive ? c.s : NEG; Cm[s] = c.nm; Cx[s] = c.nx;
+            if (!alive) Ds[s] = NEG;
+            if (alive) {
+                amask |= 1u << s;
+                if (c.s > rb.s) { rb.s = c.s; rb.j = jb + s; rb.nm = c.nm; rb.nx = c.nx; }
+            }
+        }
+        // publish: boundary cell for the next row, first / last live column, best cell
+        if (lane == 63) sh.bnd[par ^ 1u][wave] = Cell{Cs[WS - 1], Cm[WS - 1], Cx[WS - 1]};
+        const uint64_t ball = __ballot(amask != 0);
+        uint32_t wfirst = 0xFFFFFFFFu, wlast = 0;
+        if (ball) {
+            const uint32_t lf = (uint32_t)__builtin_ctzll(ball), ll = 63u - (uint32_t)__builtin_clzll(ball);
+            const uint32_t mf = (uint32_t)__builtin_amdgcn_readlane((int)amask, (int)lf);
+            const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)amask, (int)ll);
+            const uint32_t cb = wb + rw * C4_WCOLS;
+            wfirst = cb + lf * WS + (uint32_t)__builtin_ctz(mf);
+            wlast = cb + ll * WS + (31u - (uint32_t)__builtin_clz(ml));
+        }
+        Best4 wbest{NEG, 0xFFFFFFFFu, 0, 0};
+        if (__ballot(rb.s > best.score)) wbest = wave_best(rb);
+        if (lane == 0) { sh.first[wave] = wfirst; sh.last[wave] = wlast; sh.best[wave] = wbest; }
+        __syncthreads();
+        uint32_t first = 0xFFFFFFFFu, last = 0;
+        Best4 tb{NEG, 0xFFFFFFFFu, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            first = min(first, sh.first[w]);
+            last = max(last, sh.last[w]);
+            const Best4 o = sh.best[w];
+            if (o.s > tb.s || (o.s == tb.s && o.j < tb.j)) tb = o;
+        }
+        if (first == 0xFFFFFFFFu) break;
+        if (last - wb >= 4 * C4_WCOLS - WS) { best.overflow = 1; break; }
+        best.maxcols = max(best.maxcols, last - wb + 1);
+        best.rows = i;
+        if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.nm; best.nx = tb.nx; }
+        // slide the window by whole 256-column blocks: the ring of wavefronts rotates
+        const uint32_t k = (first - wb) / C4_WCOLS;
+        if (k) {
+            const bool fresh = rw < k;  // my block left the window: I re-enter on the right with new columns
+            wb += k * C4_WCOLS;
+            wbase = (wbase + k) & 3u;
+            rw = (wave - wbase) & 3u;
+            jb = wb + rw * C4_WCOLS + lane * WS;
+            if (fresh) {
+#pragma unroll
+                for (int s = 0; s < WS; s++) { Cs[s] = NEG; Ds[s] = NEG; }
+                load_qbits<WS>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+                if (lane == 63) sh.bnd[par ^ 1u][wave] = Cell{NEG, 0, 0};
+            }
+            __syncthreads();
+        }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(C4_THREADS) void k6_dp4(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
+                                                     HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+    __shared__ C4Shared sh;
+    const DpJob job = jobs[blockIdx.x];
+    const Group &G = groups[job.group];
+    HalfResult r = block_half_extend(sh, G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    if (threadIdx.x == 0) res[blockIdx.x] = r;
+}
+
 // Anchor = centre of the best 31-column window of the HSP (first maximum).  Windows are cut into
 // chunks of ANCHOR_CHUNK starts; a wave scans one chunk (each lane slides over 64 consecutive
 // starts) and folds its best (sum, start) into a packed 64-bit word with atomicMax — high half
@@ -373,7 +573,9 @@ __global__ __launch_bounds__(64) void k6_pick(Group *__restrict__ groups, const 
 }
 
 __global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
-                                            HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+                                            HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y,
+                                            int only_overflowed) {
+    if (only_overflowed && !res[blockIdx.x].overflow) return;
     const DpJob job = jobs[blockIdx.x];
     const Group &G = groups[job.group];
     HalfResult r = wave_half_extend<16>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
@@ -506,8 +708,13 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (h[0]) {
+                static int dp4_max = getenv("MIMEO_K6_DP4_MAX") ? atoi(getenv("MIMEO_K6_DP4_MAX")) : 1 << 30;
+                const bool use4 = (int)h[0] <= dp4_max;  // measured faster in both regimes (C2: 150 -> 126 ms; 1/8 shard: 59 -> 42 ms)
+                if (use4)
+                    hipLaunchKernelGGL(k6_dp4, dim3(h[0]), dim3(C4_THREADS), 0, st, (const Group *)d_groups,
+                                       (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
                 hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
-                                   (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+                                   (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0);
                 hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
                                    (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
             }
