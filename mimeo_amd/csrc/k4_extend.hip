@@ -116,7 +116,8 @@ __device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, Wa
 }
 
 __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, StrandView Q,
-                                                              const uint2 *__restrict__ hits, uint64_t nhits,
+                                                              const uint2 *__restrict__ hits, uint64_t nhits_arg,
+                                                              const unsigned long long *__restrict__ nhits_dev,
                                                               int xdrop, int hspthresh, int transitions,
                                                               const uint32_t *__restrict__ group_tab,
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, S
     __shared__ uint32_t tab[GROUP_TAB];
     for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
     __syncthreads();
+    const uint64_t nhits = nhits_dev ? (uint64_t)*nhits_dev : nhits_arg;  // count produced by an earlier kernel
     for (uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x; gid < nhits;
          gid += (uint64_t)gridDim.x * EXT_THREADS) {
         const uint2 h = hits[gid];
@@ -620,9 +622,9 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_long(StrandView T, Stra
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                               uint64_t cand_cap, uint64_t *__restrict__ fkey,
                                                               uint32_t *__restrict__ fprev) {
-    uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
-    if (wid >= ctr->nlong) return;
-    wave_extend_emit(T, Q, longq[wid], xdrop, hspthresh, transitions, true, ctr, cand, cand_cap, fkey, fprev, nullptr);
+    const uint64_t nlong = ctr->nlong, nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
+    for (uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; wid < nlong; wid += nwaves)
+        wave_extend_emit(T, Q, longq[wid], xdrop, hspthresh, transitions, true, ctr, cand, cand_cap, fkey, fprev, nullptr);
 }
 
 // ---- K4c: follower segments ----------------------------------------------------------------
@@ -661,7 +663,8 @@ constexpr uint32_t SMALL_SEG = 8;
 __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(StrandView T, StrandView Q,
                                                                 const uint64_t *__restrict__ key,
                                                                 const uint32_t *__restrict__ prev, uint64_t nfollow,
-                                                                const uint64_t *__restrict__ seg_start, uint64_t nseg,
+                                                                const uint64_t *__restrict__ seg_start,
+                                                                const uint64_t *__restrict__ nseg_dev,
                                                                 int xdrop, int hspthresh,
                                                                 const uint32_t *__restrict__ group_tab,
                                                                 ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(StrandView T, St
     __shared__ uint32_t tab[GROUP_TAB];
     for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
     __syncthreads();
+    const uint64_t nseg = *nseg_dev;
     const uint64_t sid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
     if (sid >= nseg) return;
     const uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
@@ -710,12 +714,13 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T,
                                                                    const uint64_t *__restrict__ key,
                                                                    const uint32_t *__restrict__ prev, uint64_t nfollow,
                                                                    const uint64_t *__restrict__ seg_start,
-                                                                   uint64_t nseg, const uint64_t *__restrict__ list,
-                                                                   uint64_t nlist, int xdrop, int hspthresh,
+                                                                   const uint64_t *__restrict__ nseg_dev,
+                                                                   const uint64_t *__restrict__ list, int xdrop,
+                                                                   int hspthresh,
                                                                    int transitions, ExtCounters *__restrict__ ctr,
                                                                    Cand *__restrict__ cand, uint64_t cand_cap) {
-    uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
-    if (wid >= nlist) return;
+    const uint64_t nseg = *nseg_dev, nlist = ctr->nbig, nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
+    for (uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; wid < nlist; wid += nwaves) {
     const uint64_t sid = list[wid];
     uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
     uint64_t k0 = key[beg];
@@ -741,15 +746,16 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T,
         reach = et + rext;
         i = nxt + 1;
     }
+    }
 }
 
 // ---- K4d: entropy adjustment + threshold, one wavefront per candidate --------------------
 __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandView Q, const Cand *__restrict__ cand,
-                                                          uint64_t ncand, int hspthresh, int entropy,
+                                                          uint64_t cand_cap, int hspthresh, int entropy,
                                                           ExtCounters *__restrict__ ctr, mimeo_hsp *__restrict__ out) {
-    uint64_t cid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6;
-    if (cid >= ncand) return;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t ncand = min((uint64_t)ctr->ncand, cand_cap), nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
+    for (uint64_t cid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; cid < ncand; cid += nwaves) {
     Cand c = cand[cid];
     int64_t adj = c.raw;
     if (entropy) {
@@ -786,6 +792,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
         h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = c.raw;
         out[i] = h;
     }
+    }
 }
 
 // ---- host orchestration ---------------------------------------------------------------------
@@ -814,16 +821,23 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, st));
-    uint64_t cand_cap = nhits / 4 + 65536;
+    // Candidates are rare (~1e-4 of the hits on random sequence): a modest buffer, and a rerun with the
+    // exact size in the rare overflow case.  Kernels that consume a queue read its length from device
+    // memory and run on fixed grids, so one host synchronisation (follower count, needed to size the
+    // sort) and a final one are all a unit costs.
+    uint64_t cand_cap = nhits / 32 + 65536;
     int rc;
     ExtCounters c;
     for (int attempt = 0;; attempt++) {
         if ((rc = W.cand.reserve(cand_cap * sizeof(Cand)))) return rc;
+        if ((rc = out_hsps.reserve(cand_cap * sizeof(mimeo_hsp)))) return rc;
         if ((rc = W.fkey.reserve(nhits * 8))) return rc;
         if ((rc = W.fprev.reserve(nhits * 4))) return rc;
         if ((rc = W.longq.reserve(nhits * 8))) return rc;
         if ((rc = W.medq.reserve(nhits * 8))) return rc;
+        if ((rc = W.nsel.reserve(16))) return rc;
         HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+        HIP_TRY(hipMemsetAsync(W.nsel.p, 0, 16, st));
         uint64_t nb = (nhits + FAST_THREADS - 1) / FAST_THREADS;
         if (nb > 256 * 16) nb = 256 * 16;  // grid-stride: the LDS table is loaded once per workgroup
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
@@ -831,39 +845,30 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
                            p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p)
         if (variant == 0)
-            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits, p->xdrop,
-                               p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
-                               (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits,
+                               (const unsigned long long *)nullptr, p->xdrop, p->hspthresh, p->transitions,
+                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                               (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
         else if (variant == 2) K4_LAUNCH(2);
         else if (variant == 3) K4_LAUNCH(3);
         else K4_LAUNCH(1);
+        // walks still alive after the frame -> generic kernel; beyond LONG_WINDOWS -> wavefront kernel
+        hipLaunchKernelGGL(k4_extend_generic, dim3(2048), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.medq.p,
+                           (uint64_t)0, (const unsigned long long *)&W.ctr->nmed, p->xdrop, p->hspthresh, p->transitions,
+                           (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                           (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+        hipLaunchKernelGGL(k4_extend_long, dim3(64), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.longq.p, p->xdrop,
+                           p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                           (uint32_t *)W.fprev.p);
         HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (c.nmed) {
-            uint64_t nbm = (c.nmed + EXT_THREADS - 1) / EXT_THREADS;
-            if (nbm > 256 * 32) nbm = 256 * 32;
-            hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)nbm), dim3(EXT_THREADS), 0, st, T, Q,
-                               (const uint2 *)W.medq.p, (uint64_t)c.nmed, p->xdrop, p->hspthresh, p->transitions,
-                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
-                               (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
-            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
-        if (c.nlong) {
-            uint64_t nbl = (c.nlong * 64 + EXT_THREADS - 1) / EXT_THREADS;
-            hipLaunchKernelGGL(k4_extend_long, dim3((uint32_t)nbl), dim3(EXT_THREADS), 0, st, T, Q,
-                               (const uint2 *)W.longq.p, p->xdrop, p->hspthresh, p->transitions, W.ctr,
-                               (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p);
-            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
         if (c.nfollow) {
             uint64_t nf = c.nfollow;
             if ((rc = W.fkey2.reserve(nf * 8))) return rc;
             if ((rc = W.fprev2.reserve(nf * 4))) return rc;
             if ((rc = W.flags.reserve(nf))) return rc;
             if ((rc = W.segs.reserve(nf * 8))) return rc;
-            if ((rc = W.nsel.reserve(16))) return rc;
+            if ((rc = W.bigseg.reserve(nf * 8))) return rc;
             size_t t1 = 0, t2 = 0;
             HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)W.fkey.p, (uint64_t *)W.fkey2.p,
                                               (uint32_t *)W.fprev.p, (uint32_t *)W.fprev2.p, (size_t)nf, 0, 64, st));
@@ -877,40 +882,23 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
                                (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf, (uint8_t *)W.flags.p);
             HIP_TRY(rocprim::select(W.tmp.p, t2, iota, (uint8_t *)W.flags.p, (uint64_t *)W.segs.p,
                                     (uint64_t *)W.nsel.p, (size_t)nf, st));
-            uint64_t nseg = 0;
-            HIP_TRY(hipMemcpyAsync(&nseg, W.nsel.p, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (nseg) {
-                if ((rc = W.bigseg.reserve(nseg * 8))) return rc;
-                hipLaunchKernelGGL(k4_resolve_small, dim3((uint32_t)((nseg + EXT_THREADS - 1) / EXT_THREADS)),
-                                   dim3(EXT_THREADS), 0, st, T, Q, (const uint64_t *)W.fkey2.p,
-                                   (const uint32_t *)W.fprev2.p, nf, (const uint64_t *)W.segs.p, nseg, p->xdrop,
-                                   p->hspthresh, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap,
-                                   (uint64_t *)W.bigseg.p);
-                HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (c.nbig) {
-                    uint64_t nbs = (c.nbig * 64 + EXT_THREADS - 1) / EXT_THREADS;
-                    hipLaunchKernelGGL(k4_resolve_segments, dim3((uint32_t)nbs), dim3(EXT_THREADS), 0, st, T, Q,
-                                       (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
-                                       (const uint64_t *)W.segs.p, nseg, (const uint64_t *)W.bigseg.p,
-                                       (uint64_t)c.nbig, p->xdrop, p->hspthresh, p->transitions, W.ctr,
-                                       (Cand *)W.cand.p, cand_cap);
-                }
-            }
-            HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            // segments: at most nf of them; the kernels read the real number from W.nsel
+            hipLaunchKernelGGL(k4_resolve_small, dim3((uint32_t)((nf + EXT_THREADS - 1) / EXT_THREADS)), dim3(EXT_THREADS), 0,
+                               st, T, Q, (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
+                               (const uint64_t *)W.segs.p, (const uint64_t *)W.nsel.p, p->xdrop, p->hspthresh,
+                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.bigseg.p);
+            hipLaunchKernelGGL(k4_resolve_segments, dim3(256), dim3(EXT_THREADS), 0, st, T, Q, (const uint64_t *)W.fkey2.p,
+                               (const uint32_t *)W.fprev2.p, nf, (const uint64_t *)W.segs.p, (const uint64_t *)W.nsel.p,
+                               (const uint64_t *)W.bigseg.p, p->xdrop, p->hspthresh, p->transitions, W.ctr,
+                               (Cand *)W.cand.p, cand_cap);
         }
+        hipLaunchKernelGGL(k4_entropy, dim3(512), dim3(EXT_THREADS), 0, st, T, Q, (const Cand *)W.cand.p, cand_cap,
+                           p->hspthresh, p->entropy, W.ctr, (mimeo_hsp *)out_hsps.p);
+        HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         if (c.ncand <= cand_cap) break;
         if (attempt) { set_error("candidate buffer overflow"); return MIMEO_ERR_LIMIT; }
         cand_cap = c.ncand + 1024;  // rerun with room for every candidate
-    }
-    if ((rc = out_hsps.reserve((c.ncand ? c.ncand : 1) * sizeof(mimeo_hsp)))) return rc;
-    if (c.ncand) {
-        uint64_t nbc = (c.ncand * 64 + EXT_THREADS - 1) / EXT_THREADS;
-        hipLaunchKernelGGL(k4_entropy, dim3((uint32_t)nbc), dim3(EXT_THREADS), 0, st, T, Q, (const Cand *)W.cand.p,
-                           (uint64_t)c.ncand, p->hspthresh, p->entropy, W.ctr, (mimeo_hsp *)out_hsps.p);
-        HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipStreamSynchronize(st));
