@@ -204,14 +204,21 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
     bool act = !w.done, slow = false;
     uint32_t slow_pos = 0;
     const uint32_t blocked = mnn | mH;
+    // the eight table entries depend only on the masks: fetch them back to back, then run the
+    // dependent score arithmetic on registers
+    uint32_t ent[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int pos = 4 * c;
+        ent[c] = tab[((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8)];
+    }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int pos = 4 * c;
         const bool can = act && (limit - w.k >= 4u) && !((blocked >> pos) & 0xFu);
         if (act && !can) { slow = true; slow_pos = pos; }
         act = act && can;
-        const uint32_t idx = ((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8);
-        const uint32_t e = tab[idx];
+        const uint32_t e = ent[c];
         const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
         const bool brk = act && (w.run + mn < w.best - xdrop);
         const bool go = act && !brk;
@@ -222,7 +229,6 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
         w.k = go ? w.k + 4 : w.k;
         w.done = w.done || brk;
         act = go;
-        if ((c & 1) && c < 7 && !__ballot(act)) break;  // every lane of the wavefront has stopped
     }
     if (__ballot(slow)) {
         if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, slow_pos);
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         }
         const bool last = g0 + stride >= nhits;
         if (n_med >= 64 || (last && n_med)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
             b = __shfl(b, 0);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             n_med = 0;
         }
         if (n_fol >= 64 || (last && n_fol)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
             b = __shfl(b, 0);
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             n_fol = 0;
         }
         if (n_cd >= 64 || (last && n_cd)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
             b = __shfl(b, 0);
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                 if (b + i < cand_cap) cand[b + i] = s_cd[wv][i];
             n_cd = 0;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
