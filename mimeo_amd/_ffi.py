@@ -16,7 +16,7 @@ SYMBOLS = [
     'mimeo_abi_version', 'mimeo_init', 'mimeo_shutdown', 'mimeo_last_error', 'mimeo_params_default',
     'mimeo_get_stats', 'mimeo_free', 'mimeo_genome_create', 'mimeo_genome_destroy', 'mimeo_genome_nscaf',
     'mimeo_genome_length', 'mimeo_seed_hits', 'mimeo_ungapped_hsps', 'mimeo_align_pair', 'mimeo_align_pairs',
-    'mimeo_coverage_collapse',
+    'mimeo_coverage_collapse', 'mimeo_tandem_masked',
 ]
 
 
@@ -78,6 +78,8 @@ def load():
         lib.mimeo_align_pairs.argtypes = [vp, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]
     if hasattr(lib, 'mimeo_coverage_collapse'):
         lib.mimeo_coverage_collapse.argtypes = [vp, u64, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)]
+    if hasattr(lib, 'mimeo_tandem_masked'):
+        lib.mimeo_tandem_masked.argtypes = [vp, vp, u64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     if lib.mimeo_abi_version() != ABI_VERSION:
         raise RuntimeError('libmimeo_hip.so ABI %d != expected %d' % (lib.mimeo_abi_version(), ABI_VERSION))
     _lib = lib

@@ -112,3 +112,18 @@ def coverage_collapse(intervals, chrom_len, min_cov, min_len):
     _ffi.check(_ffi.load().mimeo_coverage_collapse(iv.ctypes.data if iv.size else None, iv.size, cl.ctypes.data,
                                                    cl.size, int(min_cov), int(min_len), C.byref(ptr), C.byref(n)))
     return _ffi.take(ptr, n, _ffi.INTERVAL)
+
+
+def tandem_masked(A, intervals, match=2, mismatch=7, minscore=50, maxperiod=50):
+    """Bases of each (scaffold id, start, end) slice of genome A marked by the tandem scorer (K8)."""
+    iv = np.asarray(intervals)
+    if iv.dtype != _ffi.INTERVAL:
+        a = np.asarray(iv, dtype=np.uint32).reshape(-1, 3)
+        iv = np.zeros(a.shape[0], dtype=_ffi.INTERVAL)
+        iv['chrom'], iv['start'], iv['end'] = a[:, 0], a[:, 1], a[:, 2]
+    iv = np.ascontiguousarray(iv)
+    out = np.zeros(iv.size, dtype=np.uint32)
+    if iv.size:
+        _ffi.check(_ffi.load().mimeo_tandem_masked(A._h, iv.ctypes.data, iv.size, int(match), int(mismatch),
+                                                   int(minscore), int(maxperiod), out.ctypes.data))
+    return out

@@ -149,3 +149,22 @@ def gff_map_lines(rows, chrlens=None, ftype='BHit'):
     for r in rows:
         attributes = ';'.join(['ID=' + r[10], 'identity=' + str(r[9]), 'B_locus=' + r[4] + '_' + r[5] + '_' + str(r[6]) + '_' + str(r[7])])
         yield '\t'.join([r[0], 'mimeo-map', ftype, str(r[2]), str(r[3]), str(r[8]), r[1], '.', attributes + '\n'])
+
+
+def renumber(rows, prefix=None):
+    """UIDs after a filter (wrappers.py:243-259): same string sort as import_Align, then rank."""
+    rows = sorted((r[:10] for r in rows), key=lambda f: (f[0], f[2], f[3], f[1]))
+    width = len(str(len(rows)))
+    pre = str(prefix) if prefix else 'BHit'
+    return [f + ['%s_%s' % (pre, str(i).zfill(width))] for i, f in enumerate(rows, 1)]
+
+
+def write_trf_tab(rows, outtab):
+    """wrappers.py:380-440 writetrf: the filtered hits in the 10-column TAB layout, `<outtab>.trf`."""
+    outfile = outtab + '.trf'
+    with open(outfile, 'w') as f:
+        f.write('\t'.join(['#name1', 'strand1', 'start1', 'end1', 'name2', 'strand2', 'start2+', 'end2+', 'score',
+                           'identity']) + '\n')
+        for r in rows:
+            f.write('\t'.join(r[:10]) + '\n')
+    return outfile

@@ -26,11 +26,6 @@ def main(argv=None):
     args = mainArgs(argv)
     dist, outdir = _cli.start(args)
     logging.info('Starting genome mapping workflow.')
-    if args.maxtandem:
-        # reference: wrappers.py:120-262 trfFilter runs the external TRF binary.  The on-GPU
-        # tandem scorer that replaces it is SURVEY §8(f)-1 ("next"); refuse rather than skip silently.
-        logging.error('--maxtandem needs the tandem scorer, which is not part of this build yet.')
-        sys.exit(1)
     an, aseq = _cli.load_genome(args.afasta, args.adir, 'A')
     bn, bseq = _cli.load_genome(args.bfasta, args.bdir, 'B')
     outtab = os.path.join(outdir, args.outfile)
@@ -49,6 +44,13 @@ def main(argv=None):
             logging.warning('No alignments found in %s' % outtab)
             sys.exit(1)
         rows = formats.import_align(rows, prefix=args.prefix, min_len=args.minLen, min_idt=args.minIdt)
+        if args.maxtandem:  # run_map.py:293-314: tandem filter, optional .trf table
+            logging.info('Filtering alignments by tandem repeat content...')
+            rows = workflow.trf_filter(rows, A, prefix=args.prefix, tmatch=args.tmatch, tmismatch=args.tmismatch,
+                                       tminscore=args.tminscore, tmaxperiod=args.tmaxperiod, maxtandem=args.maxtandem)
+            if args.writeTRF:
+                logging.info('Writing TRF-filtered alignments to file: %s' % (outtab + '.trf'))
+                formats.write_trf_tab(rows, outtab)
         if args.gffout:
             gffout = os.path.join(outdir, args.gffout)
             logging.info('Writing GFF3 output to %s' % gffout)

@@ -135,3 +135,33 @@ def gff_map_lines(rows, chromlens, ftype='BHit'):
         attrs = ';'.join(['ID=' + r[10], 'identity=' + str(r[9]), 'B_locus=' + '_'.join([r[4], r[5], r[6], r[7]])])
         lines.append('\t'.join([r[0], 'mimeo-map', ftype, r[2], r[3], r[8], r[1], '.', attrs]))
     return lines
+
+
+def tandem_masked(seq, start, end, match=2, mismatch=7, minscore=50, maxperiod=50):
+    """CPU restatement of the tandem scorer v1 that stands in for
+    `trf F 2 7 7 80 10 50 50 -m -h -ngs` in wrappers.py:120-262.  PARITY UNPINNED: TRF itself is
+    absent; this restates OUR specification, not TRF's heuristics.  seq: bytes; returns the number
+    of masked bases of seq[start:end]."""
+    s = seq[start:end].upper()
+    L = len(s)
+    masked = bytearray(L)
+    ok = [c in b'ACGT' for c in s]
+    for p in range(1, maxperiod + 1):
+        if L <= p:
+            break
+        run = best = 0
+        seg = bestend = 0
+        for i in range(L - p):
+            run += match if (ok[i] and ok[i + p] and s[i] == s[i + p]) else -mismatch
+            if run <= 0:
+                if best >= minscore:
+                    for k in range(seg, min(L, bestend + p)):
+                        masked[k] = 1
+                run = best = 0
+                seg = i + 1
+            elif run > best:
+                best, bestend = run, i + 1
+        if best >= minscore:
+            for k in range(seg, min(L, bestend + p)):
+                masked[k] = 1
+    return sum(masked)

@@ -1,0 +1,89 @@
+"""K8 tandem scorer (stands in for TRF in `mimeo map --maxtandem`, wrappers.py:120-262): exact
+agreement with the CPU restatement of the same specification, and the behaviour the filter
+needs — microsatellites are masked, random sequence is not.  Agreement with TRF itself cannot be
+measured here (TRF is absent): PARITY UNPINNED."""
+import numpy as np
+import pytest
+
+from mimeo_amd.synth import synth_genome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mimeo_amd import engine
+    engine.init(0)
+    return engine
+
+
+def _with_ssrs(seed):
+    rng = np.random.default_rng(seed)
+    names, seqs = synth_genome(seed, 60_000, 2, repeat_frac=0.0)
+    out, spans = [], []
+    for s in seqs:
+        s = s.copy()
+        sp = []
+        for unit in (b'A', b'AC', b'AAG', b'ACGT', b'AAAAG', b'ACACGT', b'ACGTTGCAAC', b'ACGGTCATTGACCGTAAGCTTAGCAT'):
+            p = int(rng.integers(100, s.size - 3000))
+            ln = int(rng.integers(60, 900))
+            rep = np.frombuffer((unit * (ln // len(unit) + 1))[:ln], dtype=np.uint8).copy()
+            mut = rng.random(ln) < 0.03
+            rep[mut] = np.frombuffer(b'ACGT', np.uint8)[rng.integers(0, 4, int(mut.sum()))]
+            s[p:p + ln] = rep
+            sp.append((p, p + ln))
+        s[500:520] = ord('N')
+        s[3000:3300] |= 0x20
+        out.append(s)
+        spans.append(sp)
+    return names, out, spans
+
+
+def test_tandem_masked_equals_cpu_restatement(eng):
+    from oracle import pipeline as P
+    names, seqs, spans = _with_ssrs(3)
+    g = eng.Genome(names, seqs)
+    rng = np.random.default_rng(4)
+    iv = []
+    for c in range(2):
+        for a, b in spans[c]:
+            iv.append((c, max(0, a - int(rng.integers(0, 80))), min(len(seqs[c]), b + int(rng.integers(0, 80)))))
+        for _ in range(12):
+            a = int(rng.integers(0, len(seqs[c]) - 2500))
+            iv.append((c, a, a + int(rng.integers(1, 2400))))
+    iv += [(0, 10, 10), (0, 5, 6), (1, 29990, 40000), (0, 495, 530)]
+    for params in ((2, 7, 50, 50), (2, 5, 30, 12), (3, 7, 80, 64)):
+        got = eng.tandem_masked(g, np.array(iv, dtype=np.uint32), *params)
+        exp = [P.tandem_masked(seqs[c].tobytes(), s, min(e, len(seqs[c])), *params) for c, s, e in iv]
+        assert got.tolist() == exp, params
+    g.close()
+
+
+def test_ssr_masked_random_not(eng):
+    names, seqs, spans = _with_ssrs(5)
+    g = eng.Genome(names, seqs)
+    ssr = [(0, a, b) for a, b in spans[0]]
+    m = eng.tandem_masked(g, np.array(ssr, dtype=np.uint32))
+    frac = m / np.array([b - a for _, a, b in ssr])
+    assert (frac[:6] > 0.85).all(), frac  # periods 1..6 are masked almost entirely
+    rnd = [(1, a, a + 1000) for a in range(5000, 25000, 1000) if not any(x < a + 1000 and a < y for x, y in spans[1])]
+    m2 = eng.tandem_masked(g, np.array(rnd, dtype=np.uint32))
+    assert (m2 / 1000.0 < 0.05).all()
+    g.close()
+
+
+def test_trf_filter_and_writetrf(eng, tmp_path):
+    from mimeo_amd import formats, workflow
+    names, seqs, spans = _with_ssrs(6)
+    g = eng.Genome(names, seqs)
+    a, b = spans[0][2]
+    rows = [[names[0], '+', str(a), str(b), names[1], '+', '1', '500', '9999', '99.0'],
+            [names[0], '+', '20000', '21000', names[1], '-', '7', '1007', '8888', '98.5'],
+            [names[1], '+', '20000', '21500', names[0], '+', '9', '1509', '7777', '98.1']]
+    kept = workflow.trf_filter(rows, g, prefix='HGT', maxtandem=40)
+    assert [r[2] for r in kept] == ['20000', '20000'] and [r[10] for r in kept] == ['HGT_1', 'HGT_2']
+    assert len(workflow.trf_filter(rows, g, prefix='HGT', maxtandem=101)) == 3
+    out = formats.write_trf_tab(kept, str(tmp_path / 'o.tab'))
+    lines = open(out).read().split('\n')
+    assert lines[0].startswith('#name1\tstrand1') and lines[1].split('\t')[2] == '20000' and out.endswith('.tab.trf')
+    g.close()
