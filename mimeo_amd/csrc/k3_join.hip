@@ -213,6 +213,10 @@ int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf
     HIP_TRY(hipMemcpyAsync(&total, g_tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *nhits = total;
+    if (total >= (1ull << 32)) {
+        set_error("one (target, query, strand) unit yields 2^32 or more seed hits (low-complexity sequence?): not supported");
+        return MIMEO_ERR_LIMIT;
+    }
     int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g_ev[2], st));

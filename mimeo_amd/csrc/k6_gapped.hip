@@ -43,6 +43,7 @@ struct HalfResult {
 struct DpJob {
     uint32_t group, at, aq;
     int32_t dir;
+    uint32_t slot, pad;  // index of this half's HalfResult: 2 * (hsp_begin + anchor rank) + side
 };
 
 __device__ __forceinline__ Cell cmax_left(const Cell &l, const Cell &r) { return r.s > l.s ? r : l; }  // ties -> left
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(C4_THREADS) void k6_dp4(const Group *__restrict__ g
     const DpJob job = jobs[blockIdx.x];
     const Group &G = groups[job.group];
     HalfResult r = block_half_extend(sh, G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) res[job.slot] = r;
 }
 
 // Anchor = centre of the best 31-column window of the HSP (first maximum).  Windows are cut into
@@ -544,30 +545,63 @@ __device__ __forceinline__ bool in_boxes(const mimeo_alignment *aln, uint32_t n,
     return __ballot(inside) != 0;
 }
 
-// one wave per group: choose the next <= bmax anchors that are outside every accepted box
+// Anchor states.  The skip rule is ordered (an anchor is skipped iff it lies in the box of an ACCEPTED
+// anchor of lower rank), so anchors are finalised strictly in rank order by k6_resolve; what k6_pick
+// may choose freely is which unfinalised anchors get their DP in this round.  Fragments of one repeat
+// copy sit on neighbouring diagonals within a few kb and only the best-ranked one survives, so an
+// anchor that is NEAR a lower-ranked anchor whose DP is pending is deferred (twice at most): in the
+// next round it is normally inside that anchor's accepted box and never costs a DP.
+enum : uint8_t { A_NEW = 0, A_DONE = 1, A_SKIPPED = 2, A_ACCEPTED = 3 };
+constexpr uint32_t PICK_SCAN = 512;   // ranks looked at per round, from the first unfinalised one
+constexpr uint32_t NEAR_DIAG = 256, NEAR_POS = 8192, MAX_DEFER = 2;
+
+__device__ __forceinline__ bool anchors_near(uint2 a, uint2 b) {
+    int32_t da = (int32_t)a.x - (int32_t)a.y, db = (int32_t)b.x - (int32_t)b.y;
+    uint32_t dd = (uint32_t)abs(da - db), dp = a.x > b.x ? a.x - b.x : b.x - a.x;
+    return dd <= NEAR_DIAG && dp <= NEAR_POS;
+}
+
+// one wave per group
 __global__ __launch_bounds__(64) void k6_pick(Group *__restrict__ groups, const uint2 *__restrict__ anchors,
                                               const mimeo_alignment *__restrict__ aln, uint32_t bmax,
+                                              uint8_t *__restrict__ astate, uint8_t *__restrict__ adefer,
                                               DpJob *__restrict__ jobs, unsigned int *__restrict__ njobs) {
+    __shared__ uint32_t sb[MAX_BATCH];  // ranks scheduled in this round
     Group &G = groups[blockIdx.x];
     const uint64_t b0 = G.hsp_begin;
-    uint32_t next = G.next, nb = 0;
-    while (next < G.nchain && nb < bmax) {
-        uint2 a = anchors[b0 + next];
-        if (!in_boxes(aln + b0, G.nacc, a)) {
-            if (threadIdx.x == 0) G.batch[nb] = next;
-            nb++;
+    const uint32_t first = G.next, lane = threadIdx.x;
+    uint32_t nb = 0;
+    for (uint32_t r = first; r < G.nchain && nb < bmax && r - first < PICK_SCAN; r++) {
+        if (astate[b0 + r] != A_NEW) continue;  // wave-uniform; states of earlier rounds only
+        const uint2 a = anchors[b0 + r];
+        if (in_boxes(aln + b0, G.nacc, a)) {
+            if (lane == 0) astate[b0 + r] = A_SKIPPED;
+            continue;
         }
-        next++;
+        // near an unfinalised lower-ranked anchor whose DP is done (earlier rounds) or scheduled (this round)?
+        bool susp = false;
+        for (uint32_t r2 = first + lane; r2 < r; r2 += 64)
+            if (astate[b0 + r2] == A_DONE && anchors_near(a, anchors[b0 + r2])) susp = true;
+        if (lane < nb && anchors_near(a, anchors[b0 + sb[lane]])) susp = true;
+        if (__ballot(susp) && adefer[b0 + r] < MAX_DEFER) {
+            if (lane == 0) adefer[b0 + r]++;
+            continue;
+        }
+        if (lane == 0) sb[nb] = r;
+        nb++;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        G.next = next;
+    if (lane == 0) {
         G.nbatch = nb;
         unsigned int j0 = nb ? atomicAdd(njobs, 2u * nb) : 0u;
         G.job0 = j0;
         for (uint32_t k = 0; k < nb; k++) {
-            uint2 a = anchors[b0 + G.batch[k]];
-            jobs[j0 + 2 * k] = DpJob{blockIdx.x, a.x, a.y, -1};
-            jobs[j0 + 2 * k + 1] = DpJob{blockIdx.x, a.x, a.y, +1};
+            const uint32_t r = sb[k];
+            astate[b0 + r] = A_DONE;
+            const uint2 a = anchors[b0 + r];
+            const uint32_t slot = 2u * (uint32_t)(b0 + r);
+            jobs[j0 + 2 * k] = DpJob{blockIdx.x, a.x, a.y, -1, slot, 0};
+            jobs[j0 + 2 * k + 1] = DpJob{blockIdx.x, a.x, a.y, +1, slot + 1, 0};
         }
     }
 }
@@ -575,41 +609,54 @@ __global__ __launch_bounds__(64) void k6_pick(Group *__restrict__ groups, const 
 __global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                             HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y,
                                             int only_overflowed) {
-    if (only_overflowed && !res[blockIdx.x].overflow) return;
     const DpJob job = jobs[blockIdx.x];
+    if (only_overflowed && !res[job.slot].overflow) return;
     const Group &G = groups[job.group];
     HalfResult r = wave_half_extend<16>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) res[job.slot] = r;
 }
 
 // second chance for half extensions whose band outgrew the 1024-column window: 2048 columns
 __global__ __launch_bounds__(64) void k6_dp_wide(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                                  HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
-    if (!res[blockIdx.x].overflow) return;
     const DpJob job = jobs[blockIdx.x];
+    if (!res[job.slot].overflow) return;
     const Group &G = groups[job.group];
     HalfResult r = wave_half_extend<32>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
-    if (threadIdx.x == 0) res[blockIdx.x] = r;
+    if (threadIdx.x == 0) res[job.slot] = r;
 }
 
-// one wave per group: replay the skip rule over this round's batch, in anchor order
+// one wave per group: finalise anchors in rank order as far as DP results exist
+constexpr uint32_t RESOLVE_NEW = 256;  // boxes accepted per invocation that fit the LDS list
 __global__ __launch_bounds__(64) void k6_resolve(Group *__restrict__ groups, const uint2 *__restrict__ anchors,
                                                  const HalfResult *__restrict__ res, mimeo_alignment *__restrict__ aln,
-                                                 unsigned int *__restrict__ remaining) {
-    __shared__ uint4 sbox[MAX_BATCH];  // boxes accepted in this round (tstart, tend, qstart, qend)
+                                                 uint8_t *__restrict__ astate, unsigned int *__restrict__ remaining) {
+    __shared__ uint4 sbox[RESOLVE_NEW];  // boxes accepted in this invocation (tstart, tend, qstart, qend)
     Group &G = groups[blockIdx.x];
     const uint64_t b0 = G.hsp_begin;
     const uint32_t nacc0 = G.nacc;
-    uint32_t nnew = 0, overflow = 0;
-    for (uint32_t k = 0; k < G.nbatch; k++) {
-        uint2 a = anchors[b0 + G.batch[k]];
-        bool inside = false;  // earlier rounds were already checked by k6_pick; look at this round's boxes
-        if (threadIdx.x < nnew) {
-            uint4 o = sbox[threadIdx.x];
-            inside = a.x >= o.x && a.x < o.y && a.y >= o.z && a.y < o.w;
+    uint32_t nnew = 0, overflow = 0, r = G.next;
+    for (; r < G.nchain; r++) {
+        const uint8_t st = astate[b0 + r];
+        if (st == A_SKIPPED || st == A_ACCEPTED) continue;
+        if (nnew == RESOLVE_NEW) break;
+        const uint2 a = anchors[b0 + r];
+        bool inside = in_boxes(aln + b0, nacc0, a);  // boxes of earlier invocations (visible in global memory)
+        if (!inside) {
+            bool in2 = false;
+            for (uint32_t e = threadIdx.x; e < nnew; e += 64) {
+                uint4 o = sbox[e];
+                if (a.x >= o.x && a.x < o.y && a.y >= o.z && a.y < o.w) in2 = true;
+            }
+            inside = __ballot(in2) != 0;
         }
-        if (__ballot(inside)) continue;
-        HalfResult L = res[G.job0 + 2 * k], R = res[G.job0 + 2 * k + 1];
+        if (inside) {  // also for an anchor without DP result: a deferred anchor swallowed by now never needs one
+            if (threadIdx.x == 0) astate[b0 + r] = A_SKIPPED;
+            continue;
+        }
+        if (st == A_NEW) break;  // not swallowed and no DP result yet: it is scheduled in the next round
+        const uint32_t slot = 2u * (uint32_t)(b0 + r);
+        HalfResult L = res[slot], R = res[slot + 1];
         overflow |= L.overflow | R.overflow;
         if (threadIdx.x == 0) {
             mimeo_alignment m;
@@ -620,15 +667,17 @@ __global__ __launch_bounds__(64) void k6_resolve(Group *__restrict__ groups, con
             m.id_d = L.nm + R.nm + L.nx + R.nx;
             aln[b0 + nacc0 + nnew] = m;
             sbox[nnew] = make_uint4(m.tstart, m.tend, m.qstart, m.qend);
+            astate[b0 + r] = A_ACCEPTED;
         }
         nnew++;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        G.next = r;
         G.nacc = nacc0 + nnew;
         G.nbatch = 0;
         if (overflow) G.overflow = 1;
-        if (G.next < G.nchain) atomicAdd(remaining, 1u);
+        if (r < G.nchain) atomicAdd(remaining, 1u);
     }
 }
 
@@ -679,7 +728,7 @@ __global__ void k6_finish(Group *__restrict__ groups, uint32_t ngroups, mimeo_al
     G.naln = k;
 }
 
-static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt;
+static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt, g_astate;
 
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln) {
@@ -695,7 +744,9 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         if ((rc = g_packed.reserve(nhsps * 8))) return rc;
         HIP_TRY(hipMemsetAsync(g_packed.p, 0, nhsps * 8, st));
         if ((rc = g_jobs.reserve((size_t)ngroups * bmax * 2 * sizeof(DpJob)))) return rc;
-        if ((rc = g_res.reserve((size_t)ngroups * bmax * 2 * sizeof(HalfResult)))) return rc;
+        if ((rc = g_res.reserve((size_t)nhsps * 2 * sizeof(HalfResult)))) return rc;
+        if ((rc = g_astate.reserve((size_t)nhsps * 2))) return rc;  // state | defer count
+        HIP_TRY(hipMemsetAsync(g_astate.p, 0, (size_t)nhsps * 2, st));
         if ((rc = g_cnt.reserve(16))) return rc;
         hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups, d_sorted,
                            d_order, (unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);
@@ -703,7 +754,8 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
             HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 8, st));
             unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1;
             hipLaunchKernelGGL(k6_pick, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
-                               (const mimeo_alignment *)d_aln, bmax, (DpJob *)g_jobs.p, njobs);
+                               (const mimeo_alignment *)d_aln, bmax, (uint8_t *)g_astate.p, (uint8_t *)g_astate.p + nhsps,
+                               (DpJob *)g_jobs.p, njobs);
             unsigned int h[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -719,9 +771,12 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                                    (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
             }
             if (getenv("MIMEO_K6_STATS") && h[0]) {
-                std::vector<HalfResult> hr(h[0]);
+                std::vector<DpJob> hj(h[0]);
+                std::vector<HalfResult> hall((size_t)nhsps * 2), hr(h[0]);
                 HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(hipMemcpy(hr.data(), g_res.p, (size_t)h[0] * sizeof(HalfResult), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(hj.data(), g_jobs.p, (size_t)h[0] * sizeof(DpJob), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(hall.data(), g_res.p, hall.size() * sizeof(HalfResult), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < hr.size(); k++) hr[k] = hall[hj[k].slot];
                 unsigned long long hist[9] = {0}, rows = 0, maxr = 0, shortcut = 0;
                 for (auto &r : hr) {
                     if (!r.rows) { shortcut++; continue; }
@@ -735,7 +790,7 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                     if (!r.rows && shown < 8) { fprintf(stderr, "  [k6] zero-row job: score %d i %u j %u nm %u nx %u ovf %u\n", r.score, r.i, r.j, r.nm, r.nx, r.overflow); shown++; }
             }
             hipLaunchKernelGGL(k6_resolve, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
-                               (const HalfResult *)g_res.p, d_aln, remaining);
+                               (const HalfResult *)g_res.p, d_aln, (uint8_t *)g_astate.p, remaining);
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (!h[1]) break;
