@@ -12,7 +12,7 @@ N > 1 shards the ordered pairs over ranks (contiguous, cost-balanced, target-maj
 alignment records with one all-gatherv over RCCL, and rank 0 filters + collapses: total work is
 fixed, so "scaling" is "strong".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|small|c3] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|small|c4|c3|c5|c3small|c5small] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -26,12 +26,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (seed, total bp, scaffolds)
-    'c2': (50, 50_000_000, 10),
-    'small': (50, 4_000_000, 4),
-    'c4': (1000, 1_000_000_000, 100),
+    # name: (mode, seed A, seed B, bp per genome, scaffolds per genome, minIdt, minCov)
+    'c2': ('self', 50, None, 50_000_000, 10, 80, 3),
+    'small': ('self', 50, None, 4_000_000, 4, 80, 3),
+    'c4': ('self', 1000, None, 1_000_000_000, 100, 80, 3),
+    # the other BASELINE configs, runnable for development (not bench lines; SURVEY §8 sizes)
+    'c3': ('x', 201, 202, 200_000_000, 20, 80, 5),
+    'c3small': ('x', 201, 202, 8_000_000, 4, 80, 5),
+    'c5': ('map', 1001, 1002, 1_000_000_000, 100, 98, 0),
+    'c5small': ('map', 1001, 1002, 8_000_000, 4, 98, 0),
 }
-MIN_IDT, MIN_LEN, MIN_COV = 80, 100, 3
+MIN_LEN = 100
 
 
 def split_contiguous(pairs, cost, world, rank):
@@ -48,8 +53,12 @@ def split_contiguous(pairs, cost, world, rank):
 def cpu_baseline(names, seqs, self_pair, cross_pair):
     """The C oracle (a single-thread port of the reference's lastz-driven path, oracle/) timed on a
     bounded sample of this workload — one (A,A) pair and one (A,B) pair — and extrapolated to the
-    S self pairs and S^2 - S cross pairs of the whole job."""
+    S self pairs and S^2 - S cross pairs of the whole job.  The reference runs its script serially
+    (utils.py:247), so the 1-core figure is the like-for-like one; `allcores` (SURVEY §8d ii) runs one
+    sampled cross pair per host core concurrently, i.e. the rate a pair-parallel CPU job would reach."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
+    O.lib()
     times = []
     for t, q in (self_pair, cross_pair):
         t0 = time.time()
@@ -58,9 +67,24 @@ def cpu_baseline(names, seqs, self_pair, cross_pair):
     S = len(names)
     total_s = S * times[0] + (S * S - S) * times[1]
     total_bp = sum(len(s) for s in seqs)
-    return {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
-            'sample': 'pairs %d-%d (%.1f s) and %d-%d (%.1f s) of %d ordered pairs; whole job extrapolated as '
-                      'S*t_self + (S*S-S)*t_cross = %.0f s' % (self_pair + (times[0],) + cross_pair + (times[1], S * S, total_s))}
+    out = {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
+           'sample': 'pairs %d-%d (%.1f s) and %d-%d (%.1f s) of %d ordered pairs; whole job extrapolated as '
+                     'S*t_self + (S*S-S)*t_cross = %.0f s' % (self_pair + (times[0],) + cross_pair + (times[1], S * S, total_s))}
+    # at most 16 threads: the CPU share of a one-GPU box, and it keeps this leg near half a minute
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    if cores > 1 and S > 1:
+        sample = [(t, q) for t in range(S) for q in range(S) if t != q][:cores]
+        bufs = [seqs[i].tobytes() for i in range(S)]
+        t0 = time.time()
+        with ThreadPoolExecutor(len(sample)) as ex:  # ctypes drops the GIL inside the C call
+            list(ex.map(lambda pr: O.align_pair(bufs[pr[0]], bufs[pr[1]]), sample))
+        wall = time.time() - t0
+        per_pair = wall / len(sample)  # effective seconds per cross pair with all cores busy
+        mt_s = (S * S - S) * per_pair + S * times[0] / min(cores, S)
+        out['allcores'] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': len(sample), 'kind': 'port',
+                           'sample': '%d cross pairs run concurrently on %d threads in %.1f s; whole job extrapolated to %.0f s'
+                                     % (len(sample), len(sample), wall, mt_s)}
+    return out
 
 
 def pmc_traffic(workload):
@@ -87,27 +111,36 @@ def main():
 
     from mimeo_amd import _ffi, engine, formats, workflow
     from mimeo_amd.dist import Dist
-    from mimeo_amd.synth import synth_genome
+    from mimeo_amd.synth import make_families, synth_genome
 
     dist = Dist().init()
     if dist.world != max(1, args.gpus) and dist.rank == 0:
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dist.world), file=sys.stderr)
     # MIMEO_FORCE_DEVICE lets several ranks share one GPU (rehearsing the N>1 path on a 1-GPU box)
     engine.init(int(os.environ.get('MIMEO_FORCE_DEVICE', dist.local_rank)))
-    seed, total_bp, nscaf = WORKLOADS[args.workload]
-    names, seqs = synth_genome(seed, total_bp, nscaf)
+    mode, seed, seed_b, total_bp, nscaf, MIN_IDT, MIN_COV = WORKLOADS[args.workload]
+    B = None
+    if mode == 'self':
+        names, seqs = synth_genome(seed, total_bp, nscaf)
+    else:  # two genomes carrying copies of the same repeat families
+        fams = make_families(seed, 40)
+        msat = 0.01 if mode == 'map' else 0.0
+        names, seqs = synth_genome(seed, total_bp, nscaf, shared_families=fams, prefix='a', microsat_frac=msat)
+        bnames, bseqs = synth_genome(seed_b, total_bp, nscaf, shared_families=fams, prefix='b', microsat_frac=msat)
+        B = engine.Genome(bnames, bseqs)
     A = engine.Genome(names, seqs)  # packed, device resident: outside the timed region
-    pairs = workflow.all_pairs(nscaf)
+    pairs = workflow.all_pairs(nscaf, nscaf if B is not None else None)
     L = A.lengths
+    LQ = B.lengths if B is not None else L
     ew, er = (int(args.emulate.split('/')[1]), int(args.emulate.split('/')[0])) if args.emulate else (dist.world, dist.rank)
-    mine = split_contiguous(pairs, lambda p: L[p[0]] * L[p[1]] * (3.0 if p[0] == p[1] else 1.0), ew, er)
+    mine = split_contiguous(pairs, lambda p: L[p[0]] * LQ[p[1]] * (3.0 if B is None and p[0] == p[1] else 1.0), ew, er)
     params = engine.default_params()
     names_sorted = sorted(names, key=lambda s: s.encode())
     cid = {n: i for i, n in enumerate(names_sorted)}
     lens_sorted = [L[names.index(n)] for n in names_sorted]
 
     def step():
-        alns = engine.align_pairs(A, None, mine, params) if mine else np.zeros(0, dtype=_ffi.ALIGNMENT)
+        alns = engine.align_pairs(A, B, mine, params) if mine else np.zeros(0, dtype=_ffi.ALIGNMENT)
         st = engine.stats()
         alns = dist.allgather_records(alns)
         regions = None
@@ -119,7 +152,11 @@ def main():
             a = alns[keep][pct >= MIN_IDT]
             iv = np.stack([np.array([cid[names[t]] for t in a['tid']], dtype=np.uint32).reshape(-1),
                            a['tstart'] + 1, a['tend']], 1).astype(np.uint32) if a.size else np.zeros((0, 3), np.uint32)
-            regions = engine.coverage_collapse(iv, lens_sorted, MIN_COV, MIN_LEN)
+            if mode == 'map':  # A16 has no collapse; the tandem scorer (K8) filters the target slices instead
+                m = engine.tandem_masked(A, np.stack([a['tid'], a['tstart'] + 1, a['tend']], 1).astype(np.uint32)) if a.size else np.zeros(0, np.uint32)
+                regions = a[m.astype(np.float64) * 100 < 40.0 * (a['tend'] - a['tstart'] - 1).clip(1)] if a.size else a
+            else:
+                regions = engine.coverage_collapse(iv, lens_sorted, MIN_COV, MIN_LEN)
         return st, alns, regions
 
     import torch
@@ -144,12 +181,13 @@ def main():
         b_alg = st['scan_bytes_algorithmic'] / launches        # SURVEY §8(d) B_scan per launch
         achieved = b_alg / t_fill / 1e9 if t_fill > 0 else 0.0
         line = {
-            'metric': 'Gbp-aligned/sec (mimeo self, --minIdt 80 --minLen 100 --minCov 3)',
+            'metric': 'Gbp-aligned/sec (mimeo %s, --minIdt %d --minLen %d%s)' % (mode, MIN_IDT, MIN_LEN, ' --minCov %d' % MIN_COV if MIN_COV else ' --maxtandem 40'),
             'value': total_bp / 1e9 / (ms_per_step / 1e3), 'unit': 'Gbp-aligned/s',
             'n_gpus': dist.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': '%s: mimeo-self, %d Mbp synthetic genome, %d scaffolds x %.1f Mbp, 5%% planted repeats, seed %d'
-                                   % (args.workload.upper(), total_bp // 1_000_000, nscaf, total_bp / nscaf / 1e6, seed),
+            'config': {'workload': '%s: mimeo-%s, %d Mbp synthetic genome%s, %d scaffolds x %.1f Mbp, 5%% planted repeats, seed %s'
+                                   % (args.workload.upper(), mode, total_bp // 1_000_000, '' if B is None else ' x2 (A, B)', nscaf,
+                                      total_bp / nscaf / 1e6, seed if B is None else '%d/%d' % (seed, seed_b)),
                        'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': 'pairs-sharded x%d' % dist.world},
             'roofline': {'kernel': 'k3_join_fill (seed scan)', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': pmc_traffic(args.workload), 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_seed_scan.json)',
@@ -159,10 +197,12 @@ def main():
             'counts_rank0': {k: int(st[k]) for k in ('seed_hits', 'hsps', 'chained_hsps', 'alignments')},
             'result': {'alignments': int(alns.size), 'regions': int(regions.size)},
         }
-        if not args.no_cpu_baseline and dist.world == 1:
+        if not args.no_cpu_baseline and dist.world == 1 and B is None:
             line['cpu_baseline'] = cpu_baseline(names, seqs, (0, 0), (0, 1))
         print(json.dumps(line))
     A.close()
+    if B is not None:
+        B.close()
 
 
 if __name__ == '__main__':

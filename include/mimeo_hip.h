@@ -166,6 +166,21 @@ void mimeo_genome_destroy(mimeo_genome *g);
 int mimeo_genome_nscaf(const mimeo_genome *g, uint32_t *nscaf);
 int mimeo_genome_length(const mimeo_genome *g, uint32_t scaf, uint64_t *length);
 
+/*
+ * Streaming FASTA ingest: replaces splitFasta + chromlens + the Biopython parse
+ * (src/mimeo/utils.py:274-309, 502-557; call sites run_self.py:199-224).  Every
+ * record of every file in `paths` (in order) becomes one scaffold; the record id is
+ * the first word of the header line, as Biopython's rec.id.  A host thread parses
+ * record i+1 into pinned memory while record i is copied and packed (K1).  A
+ * duplicate id is MIMEO_ERR_ARG with the reference's message (utils.py:300-306).
+ * If `split_dir` is non-NULL one `<id>.fa` per record is also written there — the
+ * side effect of the reference's --adir/--bdir.  `mimeo_genome_name` returns a
+ * pointer owned by the genome ("" for genomes made by mimeo_genome_create).
+ */
+int mimeo_genome_load_fasta(const char *const *paths, uint32_t npaths, const char *split_dir,
+                            mimeo_genome **out);
+int mimeo_genome_name(const mimeo_genome *g, uint32_t scaf, const char **name);
+
 /* ---- stage entry points (parity tests, profiling) ----------------------------- */
 
 /*

@@ -41,23 +41,38 @@ def init_logging(level):
 
 
 def load_genome(fasta, directory, what):
-    """utils.py:339-469 set_paths + :274-309 splitFasta, without the per-scaffold files: the
-    genome goes straight to the device."""
+    """utils.py:339-469 set_paths + :274-309 splitFasta: the genome is streamed from disk straight to
+    the device by the native parser (engine.Genome.from_fasta).  As in the reference, a multi-FASTA
+    given together with --adir/--bdir is also split into `<dir>/<id>.fa`; a directory alone is read
+    file by file (sorted order)."""
+    split_dir = None
     if fasta:
         if not os.path.isfile(fasta):
             logging.error('%s-genome fasta not found at path: %s' % (what, fasta))
             sys.exit(1)
-        names, seqs = formats.read_fasta(fasta)
+        paths = [fasta]
+        if directory:
+            split_dir = os.path.abspath(directory)
+            if not os.path.isdir(split_dir):
+                logging.info('Creating %sdir: %s' % (what, split_dir))
+                os.makedirs(split_dir, exist_ok=True)
     elif directory and os.path.isdir(directory):
-        names, seqs = formats.read_fasta_dir(directory)
+        paths = [os.path.join(directory, fn) for fn in sorted(os.listdir(directory))
+                 if os.path.isfile(os.path.join(directory, fn))]
     else:
         logging.error('No %s-genome fasta file provided. Quitting.' % what)
         sys.exit(1)
-    if not names:
+    try:
+        G = engine.Genome.from_fasta(paths, split_dir if Dist().rank == 0 else None)
+    except RuntimeError as e:
+        if 'Non-unique name' in str(e):  # utils.py:300-306
+            logging.error(str(e))
+            sys.exit(1)
+        raise
+    if not G.names:
         logging.error('No sequences found for genome %s \n Cannot calculate seq lengths.' % what)
         sys.exit(1)
-    formats.check_unique(names)
-    return names, seqs
+    return G
 
 
 def start(args):

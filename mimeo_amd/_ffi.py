@@ -16,7 +16,7 @@ SYMBOLS = [
     'mimeo_abi_version', 'mimeo_init', 'mimeo_shutdown', 'mimeo_last_error', 'mimeo_params_default',
     'mimeo_get_stats', 'mimeo_free', 'mimeo_genome_create', 'mimeo_genome_destroy', 'mimeo_genome_nscaf',
     'mimeo_genome_length', 'mimeo_seed_hits', 'mimeo_ungapped_hsps', 'mimeo_align_pair', 'mimeo_align_pairs',
-    'mimeo_coverage_collapse', 'mimeo_tandem_masked',
+    'mimeo_coverage_collapse', 'mimeo_tandem_masked', 'mimeo_genome_load_fasta', 'mimeo_genome_name',
 ]
 
 
@@ -69,6 +69,8 @@ def load():
     lib.mimeo_genome_destroy.restype = None
     lib.mimeo_genome_nscaf.argtypes = [vp, C.POINTER(u32)]
     lib.mimeo_genome_length.argtypes = [vp, u32, C.POINTER(u64)]
+    lib.mimeo_genome_load_fasta.argtypes = [C.POINTER(C.c_char_p), u32, C.c_char_p, C.POINTER(vp)]
+    lib.mimeo_genome_name.argtypes = [vp, u32, C.POINTER(C.c_char_p)]
     for name in ('mimeo_seed_hits', 'mimeo_ungapped_hsps'):
         if hasattr(lib, name):
             getattr(lib, name).argtypes = [vp, u32, vp, u32, u32, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]

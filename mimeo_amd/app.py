@@ -1,8 +1,9 @@
-"""`mimeo <x|self|map> ...` dispatcher (reference: src/mimeo/app.py:21-63)."""
+"""`mimeo <x|self|map|filter> ...` dispatcher (reference: src/mimeo/app.py:21-63)."""
 import sys
 from importlib import import_module
 
-COMMANDS = {'x': 'mimeo_amd.run_interspecies', 'self': 'mimeo_amd.run_self', 'map': 'mimeo_amd.run_map'}
+COMMANDS = {'x': 'mimeo_amd.run_interspecies', 'self': 'mimeo_amd.run_self', 'map': 'mimeo_amd.run_map',
+            'filter': 'mimeo_amd.run_filter'}
 
 
 def print_usage():
@@ -13,6 +14,7 @@ Commands:
   x       Run cross-species comparison
   self    Run self-alignment analysis
   map     Run genomic mapping
+  filter  Run filtering operations
 
 For command-specific help:
   mimeo <command> --help

@@ -133,6 +133,19 @@ int mimeo_genome_nscaf(const mimeo_genome *g, uint32_t *nscaf) {
     return MIMEO_OK;
 }
 
+int mimeo_genome_load_fasta(const char *const *paths, uint32_t npaths, const char *split_dir, mimeo_genome **out) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!out || (!paths && npaths)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    return load_fasta_impl(paths, npaths, split_dir, out);
+}
+
+int mimeo_genome_name(const mimeo_genome *g, uint32_t scaf, const char **name) {
+    if (!g || !name || scaf >= g->scaf.size()) { set_error("bad scaffold id"); return MIMEO_ERR_ARG; }
+    *name = scaf < g->names.size() ? g->names[scaf].c_str() : "";
+    return MIMEO_OK;
+}
+
 int mimeo_genome_length(const mimeo_genome *g, uint32_t scaf, uint64_t *length) {
     if (!g || !length || scaf >= g->scaf.size()) { set_error("bad scaffold id"); return MIMEO_ERR_ARG; }
     *length = g->scaf[scaf].len;
@@ -162,7 +175,8 @@ int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, 
     DeviceBuf hits;
     uint64_t n = 0;
     JoinTiming tm;
-    rc = join_hits(it.view(), iq.view(), p->transitions, hits, &n, &tm);
+    static JoinCtx jc;
+    rc = join_hits(jc, it.view(), iq.view(), p->transitions, hits, &n, &tm);
     if (!rc) {
         mimeo_seed_hit *h = (mimeo_seed_hit *)malloc((n ? n : 1) * sizeof(mimeo_seed_hit));
         if (!h) { set_error("host allocation failed"); rc = MIMEO_ERR_NOMEM; }
@@ -204,8 +218,10 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
     do {
         if ((rc = build_index(tv, it, &ms_index))) break;
         if ((rc = build_index(qv, iq, &ms_index))) break;
-        if ((rc = join_hits(it.view(), iq.view(), p->transitions, hits, &n, &tm))) break;
-        if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)hits.p, n, p, hsps, &nh, &ms_ext))) break;
+        static JoinCtx jc;
+        static ExtWork ew;
+        if ((rc = join_hits(jc, it.view(), iq.view(), p->transitions, hits, &n, &tm))) break;
+        if ((rc = ungapped_hsps_device(ew, tv, qv, (const uint2 *)hits.p, n, p, hsps, &nh, &ms_ext))) break;
         h = (mimeo_hsp *)malloc((nh ? nh : 1) * sizeof(mimeo_hsp));
         if (!h) { set_error("host allocation failed"); rc = MIMEO_ERR_NOMEM; break; }
         if (nh) {

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,7 @@ struct Scaffold {
 
 struct mimeo_genome {
     std::vector<mimeo::Scaffold> scaf;
+    std::vector<std::string> names;  // record ids when loaded from FASTA (ingest.hip); else empty
 };
 
 namespace mimeo {
@@ -99,6 +101,9 @@ bool initialised();
 int pack_scaffold(const uint8_t *d_ascii, uint64_t len, Scaffold &out);
 void free_scaffold(Scaffold &s);
 
+// streaming FASTA ingest (ingest.hip)
+int load_fasta_impl(const char *const *paths, uint32_t npaths, const char *split_dir, mimeo_genome **out);
+
 // K2: seed index of one strand (k2_index.hip)
 int build_index(const StrandView &s, SeedIndex &out, float *ms);
 
@@ -111,12 +116,27 @@ struct DeviceBuf {
     void release();
 };
 struct JoinTiming { float ms_count = 0, ms_fill = 0; };
-int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
+// per-lane work state of K3 (a lane = one host thread + one stream working through units)
+struct JoinCtx {
+    unsigned long long *tile_count = nullptr, *tile_base = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void release();
+};
+int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
               JoinTiming *tm);
 
 // K4: seed hits -> HSPs (k4_extend.hip); out_hsps holds mimeo_hsp records on the device
-int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
-                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms);
+struct ExtCounters;
+struct ExtWork {  // per-lane work state of K4
+    ExtCounters *ctr = nullptr;  // device
+    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel, bigseg;
+    void release();
+};
+// `after_fast` (optional) is called once, right after the fast kernel of the first attempt has been
+// launched: the point where a concurrent lane may start its own heavy phase.
+int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
+                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
+                         const std::function<void()> *after_fast = nullptr);
 
 // K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
 constexpr int MAX_BATCH = 32;

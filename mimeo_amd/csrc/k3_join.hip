@@ -190,20 +190,23 @@ void DeviceBuf::release() {
     cap = 0;
 }
 
-static unsigned long long *g_tile_count = nullptr, *g_tile_base = nullptr;
-static hipEvent_t g_ev[4];
-static bool g_ev_ok = false;
+void JoinCtx::release() {
+    if (tile_count) (void)hipFree(tile_count);
+    if (tile_base) (void)hipFree(tile_base);
+    tile_count = tile_base = nullptr;
+    for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+}
 
-int join_hits(const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
+int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
               JoinTiming *tm) {
-    if (!g_tile_count) {
-        HIP_TRY(hipMalloc((void **)&g_tile_count, (NTILE + 2) * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc((void **)&g_tile_base, (NTILE + 2) * sizeof(unsigned long long)));
+    if (!ctx.tile_count) {
+        HIP_TRY(hipMalloc((void **)&ctx.tile_count, (NTILE + 2) * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&ctx.tile_base, (NTILE + 2) * sizeof(unsigned long long)));
     }
-    if (!g_ev_ok) {
-        for (auto &e : g_ev) HIP_TRY(hipEventCreate(&e));
-        g_ev_ok = true;
-    }
+    if (!ctx.ev[0])
+        for (auto &e : ctx.ev) HIP_TRY(hipEventCreate(&e));
+    unsigned long long *g_tile_count = ctx.tile_count, *g_tile_base = ctx.tile_base;
+    hipEvent_t *g_ev = ctx.ev;
     hipStream_t st = stream();
     HIP_TRY(hipEventRecord(g_ev[0], st));
     hipLaunchKernelGGL(k3_join_count, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, Q.off, transitions, g_tile_count);

@@ -20,6 +20,7 @@
 //   * k4_entropy applies the entropy adjustment to candidates and the threshold.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -802,25 +803,33 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
 }
 
 // ---- host orchestration ---------------------------------------------------------------------
-struct ExtWork {
-    ExtCounters *ctr = nullptr;  // device
-    uint32_t *group_tab = nullptr;  // device copy of the 4-base group table
-    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel, bigseg;
-};
-static ExtWork W;
+static uint32_t *g_group_tab = nullptr;  // device copy of the 4-base group table (read-only, shared by all lanes)
+static std::once_flag g_group_once;
 
-int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
-                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms) {
+void ExtWork::release() {
+    if (ctr) (void)hipFree(ctr);
+    ctr = nullptr;
+    for (DeviceBuf *b : {&cand, &fkey, &fkey2, &fprev, &fprev2, &longq, &medq, &flags, &segs, &tmp, &nsel, &bigseg}) b->release();
+}
+
+int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
+                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
+                         const std::function<void()> *after_fast) {
     hipStream_t st = stream();
     *nhsp = 0;
     if (T.len >= 0x7FFFFF00u || Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
     if (!W.ctr) HIP_TRY(hipMalloc((void **)&W.ctr, sizeof(ExtCounters)));
-    if (!W.group_tab) {
+    int tab_rc = 0;
+    std::call_once(g_group_once, [&] {
         std::vector<uint32_t> tab(GROUP_TAB);
         build_group_table(tab.data());
-        HIP_TRY(hipMalloc((void **)&W.group_tab, GROUP_TAB * 4));
-        HIP_TRY(hipMemcpy(W.group_tab, tab.data(), GROUP_TAB * 4, hipMemcpyHostToDevice));
-    }
+        if (hipMalloc((void **)&g_group_tab, GROUP_TAB * 4) != hipSuccess ||
+            hipMemcpy(g_group_tab, tab.data(), GROUP_TAB * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            g_group_tab = nullptr;
+            tab_rc = MIMEO_ERR_HIP;
+        }
+    });
+    if (tab_rc || !g_group_tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
     HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
     if (!nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
     hipEvent_t e0, e1;
@@ -848,20 +857,21 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
         if (nb > 256 * 16) nb = 256 * 16;  // grid-stride: the LDS table is loaded once per workgroup
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
-                           p->hspthresh, p->transitions, (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
+                           p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p)
         if (variant == 0)
             hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits,
                                (const unsigned long long *)nullptr, p->xdrop, p->hspthresh, p->transitions,
-                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                               (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                                (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
         else if (variant == 2) K4_LAUNCH(2);
         else if (variant == 3) K4_LAUNCH(3);
         else K4_LAUNCH(1);
+        if (after_fast && attempt == 0) (*after_fast)();
         // walks still alive after the frame -> generic kernel; beyond LONG_WINDOWS -> wavefront kernel
         hipLaunchKernelGGL(k4_extend_generic, dim3(2048), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.medq.p,
                            (uint64_t)0, (const unsigned long long *)&W.ctr->nmed, p->xdrop, p->hspthresh, p->transitions,
-                           (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
+                           (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                            (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
         hipLaunchKernelGGL(k4_extend_long, dim3(64), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.longq.p, p->xdrop,
                            p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
@@ -892,7 +902,7 @@ int ungapped_hsps_device(const StrandView &T, const StrandView &Q, const uint2 *
             hipLaunchKernelGGL(k4_resolve_small, dim3((uint32_t)((nf + EXT_THREADS - 1) / EXT_THREADS)), dim3(EXT_THREADS), 0,
                                st, T, Q, (const uint64_t *)W.fkey2.p, (const uint32_t *)W.fprev2.p, nf,
                                (const uint64_t *)W.segs.p, (const uint64_t *)W.nsel.p, p->xdrop, p->hspthresh,
-                               (const uint32_t *)W.group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.bigseg.p);
+                               (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.bigseg.p);
             hipLaunchKernelGGL(k4_resolve_segments, dim3(256), dim3(EXT_THREADS), 0, st, T, Q, (const uint64_t *)W.fkey2.p,
                                (const uint32_t *)W.fprev2.p, nf, (const uint64_t *)W.segs.p, (const uint64_t *)W.nsel.p,
                                (const uint64_t *)W.bigseg.p, p->xdrop, p->hspthresh, p->transitions, W.ctr,

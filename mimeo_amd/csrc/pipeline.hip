@@ -2,17 +2,19 @@
 // (src/mimeo/wrappers.py:1015-1059 in the reference): mimeo_align_pairs / mimeo_align_pair.
 //
 // Pairs are grouped by target scaffold.  A scaffold strand's seed index is built once and
-// kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  For
-// every (target, query, strand) unit K3 (index join) and K4 (gap-free extension) run one unit at a
-// time; the HSPs of up to MAX_GROUPS units are then chained and gap-extended together (K5/K6, one
-// workgroup per unit in K5, one wavefront per half extension in K6).
+// kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  Every
+// (target, query, strand) unit goes through K3 (index join) and K4 (gap-free extension) on one of
+// two lanes (host thread + stream); the HSPs of up to MAX_GROUPS units are then chained and
+// gap-extended together (K5/K6, one workgroup per unit in K5, wavefronts per half extension in K6).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <future>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <tuple>
 
 #include "common.h"
@@ -22,14 +24,18 @@ namespace mimeo {
 extern mimeo_stats g_stats;
 
 struct IndexCache {
-    // key: (scaffold address, strand, target-role sv plane in use)
+    // key: (scaffold address, strand, target-role sv plane in use).  Shared by the lanes: a build holds
+    // the lock (build_index uses one workspace and synchronises its stream before returning, so an index
+    // found in the map is complete whichever lane built it).
     std::map<std::tuple<const Scaffold *, int, int>, SeedIndex> m;
+    std::mutex mu;
     float ms = 0;
     int get(const Scaffold &s, int minus, bool as_target, IndexView *out, StrandView *sv) {
         bool tsv = as_target && !minus && s.fwd.sv_target != nullptr;
         const Strand &st = minus ? s.rc : s.fwd;
         *sv = st.view(tsv);
         auto key = std::make_tuple(&s, minus, tsv ? 1 : 0);
+        std::lock_guard<std::mutex> lk(mu);
         auto it = m.find(key);
         if (it == m.end()) {
             SeedIndex idx;
@@ -55,20 +61,46 @@ static uint64_t scan_bytes_kernel(uint64_t nT, uint64_t nQ, uint64_t H) {
     return 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 4ull * (nT + nQ) + 8ull * H;
 }
 
-static DeviceBuf g_hits, g_unit_hsps, g_hsp_batch[2], g_scratch, g_aln, g_groups;
-static hipStream_t g_stream2 = nullptr;
-// MIMEO_OVERLAP=1 runs K5/K6 of a finished batch on a second stream while the next batch goes through
-// K3/K4.  Off by default: on C2 the two phases compete for the same VALUs (step 0.585 s vs 0.561 s
-// without overlap) and the co-running kernels distort the per-kernel timings.
-static bool g_overlap = false;
+// A lane = one host thread + one stream + its own K3/K4 work buffers, taking units off a shared counter.
+// Two lanes keep the GPU busy through the host round trips and the small latency-bound kernels of a
+// unit (follower sort, segment resolution, entropy).  The heavy phase of a unit — K3 and the fast K4
+// kernel — is serialised across lanes (HeavyGate): each one starts after the previous one's fast kernel
+// has finished, so the bandwidth-bound seed scan is never sharing the chip with another scan.
+struct Lane {
+    hipStream_t st = nullptr;
+    hipEvent_t heavy_end = nullptr;
+    JoinCtx jc;
+    ExtWork ew;
+    DeviceBuf hits, unit_hsps;
+    JoinTiming tm;
+    float ms_ext = 0;
+};
+struct HeavyGate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    void acquire(hipStream_t st) {
+        mu.lock();
+        if (last) (void)hipStreamWaitEvent(st, last, 0);
+    }
+    void release(hipStream_t st, hipEvent_t mine) {
+        (void)hipEventRecord(mine, st);
+        last = mine;
+        mu.unlock();
+    }
+};
+constexpr int MAX_LANES = 4;
+static Lane g_lane[MAX_LANES];
+static DeviceBuf g_hsp_batch, g_scratch, g_aln, g_groups;
 
-// One batch of units whose HSPs are complete: K5 + K6 + read-back.  Runs on a worker thread with
-// its own stream so that the latency-bound K6 rounds of batch b overlap K3/K4 of batch b+1.
+struct Unit {
+    uint64_t pair;  // index into pair_t / pair_q
+    uint32_t tid, qid, minus;
+};
+
 struct Batch {
     std::vector<Group> groups;
     std::vector<uint64_t> group_pair;
     uint64_t nh_total = 0;
-    int buf = 0;
 };
 struct BatchResult {
     int rc = 0;
@@ -77,13 +109,9 @@ struct BatchResult {
     float ms_chain = 0, ms_gapped = 0;
 };
 
-static BatchResult run_batch(Batch b, const mimeo_params *p, std::vector<std::vector<mimeo_alignment>> *per_pair) {
+// K5 + K6 + read-back of one batch of units whose HSPs are complete
+static BatchResult run_batch(Batch &b, const mimeo_params *p, std::vector<std::vector<mimeo_alignment>> *per_pair) {
     BatchResult r;
-    (void)hipSetDevice(device_id());
-    struct StreamScope {  // the worker's launches go to the second stream; restored on every return path
-        StreamScope(hipStream_t s) { set_thread_stream(s); }
-        ~StreamScope() { set_thread_stream(nullptr); }
-    } scope(g_overlap ? g_stream2 : nullptr);
     hipStream_t st = stream();
     auto fail = [&](int rc) { r.rc = rc; r.err = last_error_copy(); return r; };
     if (!b.nh_total || b.groups.empty()) return r;
@@ -92,7 +120,7 @@ static BatchResult run_batch(Batch b, const mimeo_params *p, std::vector<std::ve
     if ((rc = g_aln.reserve(b.nh_total * sizeof(mimeo_alignment)))) return fail(rc);
     if (hipMemcpyAsync(g_groups.p, b.groups.data(), b.groups.size() * sizeof(Group), hipMemcpyHostToDevice, st) != hipSuccess)
         return fail(MIMEO_ERR_HIP);
-    if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)b.groups.size(), (const mimeo_hsp *)g_hsp_batch[b.buf].p,
+    if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)b.groups.size(), (const mimeo_hsp *)g_hsp_batch.p,
                                   b.nh_total, p, g_scratch, (mimeo_alignment *)g_aln.p, &r.ms_chain, &r.ms_gapped)))
         return fail(rc);
     std::vector<mimeo_alignment> host_aln(b.nh_total);
@@ -120,6 +148,85 @@ static BatchResult run_batch(Batch b, const mimeo_params *p, std::vector<std::ve
     return r;
 }
 
+// state shared by the lanes while one batch of units goes through K3/K4
+struct Shared {
+    const mimeo_genome *A, *QG;
+    const mimeo_params *p;
+    const std::vector<Unit> *units;
+    size_t begin, end;            // unit range of this batch
+    std::atomic<size_t> next;
+    std::atomic<int> rc{0};
+    std::string err;
+    std::mutex mu;                // batch append, stats, err
+    IndexCache *cache;
+    HeavyGate gate;
+    Batch *batch;
+};
+
+static void lane_main(Lane *ln, Shared *sh) {
+    (void)hipSetDevice(device_id());
+    set_thread_stream(ln->st);
+    hipStream_t st = ln->st;
+    const mimeo_params *p = sh->p;
+    auto fail = [&](int rc) {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        if (!sh->rc.load()) { sh->rc = rc; sh->err = last_error_copy(); }
+    };
+    for (;;) {
+        size_t ui = sh->next.fetch_add(1);
+        if (ui >= sh->end || sh->rc.load()) break;
+        const Unit &u = (*sh->units)[ui];
+        const Scaffold &ts = sh->A->scaf[u.tid], &qs = sh->QG->scaf[u.qid];
+        IndexView ti, qi;
+        StrandView tv, qv;
+        int rc;
+        if ((rc = sh->cache->get(ts, 0, true, &ti, &tv)) || (rc = sh->cache->get(qs, (int)u.minus, false, &qi, &qv))) { fail(rc); break; }
+        uint64_t nhits = 0, nh = 0;
+        bool held = true;
+        sh->gate.acquire(st);
+        std::function<void()> after_fast = [&] { if (held) { sh->gate.release(st, ln->heavy_end); held = false; } };
+        rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm);
+        if (!rc) rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, nhits, p, ln->unit_hsps, &nh, &ln->ms_ext, &after_fast);
+        after_fast();  // no hits, or an error before the fast kernel
+        if (rc) { fail(rc); break; }
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            Batch &b = *sh->batch;
+            if ((b.nh_total + nh) * sizeof(mimeo_hsp) > g_hsp_batch.cap) {
+                // grow: every lane's copies into the old buffer are issued under this lock, so a device-wide
+                // wait makes them complete
+                DeviceBuf bigger;
+                if ((rc = bigger.reserve((b.nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) { if (!sh->rc.load()) { sh->rc = rc; sh->err = last_error_copy(); } break; }
+                (void)hipDeviceSynchronize();
+                if (b.nh_total) (void)hipMemcpy(bigger.p, g_hsp_batch.p, b.nh_total * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice);
+                g_hsp_batch.release();
+                g_hsp_batch = bigger;
+            }
+            if (nh && hipMemcpyAsync((char *)g_hsp_batch.p + b.nh_total * sizeof(mimeo_hsp), ln->unit_hsps.p, nh * sizeof(mimeo_hsp),
+                                     hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                if (!sh->rc.load()) { sh->rc = MIMEO_ERR_HIP; sh->err = "hipMemcpyAsync(unit HSPs) failed"; }
+                break;
+            }
+            Group &g = b.groups[ui - sh->begin];
+            memset(&g, 0, sizeof g);
+            g.T = tv; g.Q = qv; g.tid = u.tid; g.qid = u.qid; g.minus = u.minus;
+            g.hsp_begin = b.nh_total; g.hsp_end = b.nh_total + nh;
+            b.group_pair[ui - sh->begin] = u.pair;
+            b.nh_total += nh;
+            g_stats.pair_strands++;
+            g_stats.seed_hits += nhits;
+            g_stats.hsps += nh;
+            g_stats.query_bases_scanned += qs.len;
+            g_stats.scan_bytes_algorithmic += scan_bytes_algorithmic(qs.len, nhits);
+            g_stats.scan_bytes_kernel += scan_bytes_kernel(ti.n, qi.n, nhits);
+            g_stats.scan_launches++;
+        }
+        // the copy reads unit_hsps, which the next unit of this lane overwrites: same stream, so ordered
+    }
+    (void)hipStreamSynchronize(st);
+    set_thread_stream(nullptr);
+}
+
 int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
     auto t0 = std::chrono::steady_clock::now();
@@ -127,101 +234,49 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     const mimeo_genome *QG = B ? B : A;
     for (uint64_t k = 0; k < npairs; k++)
         if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
-    if (!g_stream2) HIP_TRY(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
-    g_overlap = getenv("MIMEO_OVERLAP") && atoi(getenv("MIMEO_OVERLAP")) != 0;
-    // stable grouping of pair indices by target
+    int nlanes = getenv("MIMEO_LANES") ? atoi(getenv("MIMEO_LANES")) : 2;
+    nlanes = std::max(1, std::min(MAX_LANES, nlanes));
+    for (int l = 0; l < nlanes; l++) {
+        if (!g_lane[l].st) HIP_TRY(hipStreamCreateWithFlags(&g_lane[l].st, hipStreamNonBlocking));
+        if (!g_lane[l].heavy_end) HIP_TRY(hipEventCreateWithFlags(&g_lane[l].heavy_end, hipEventDisableTiming));
+        g_lane[l].tm = JoinTiming();
+        g_lane[l].ms_ext = 0;
+    }
+    // units in target-major order (stable in the caller's pair order): neighbouring units share the
+    // target index, and the two lanes work on neighbouring units
     std::vector<uint64_t> ord(npairs);
     for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
     std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) { return pair_t[a] < pair_t[b]; });
+    std::vector<Unit> units;
+    for (uint64_t k = 0; k < npairs; k++)
+        for (uint32_t minus = 0; minus < 2; minus++)
+            if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))
+                units.push_back(Unit{ord[k], pair_t[ord[k]], pair_q[ord[k]], minus});
     std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
     IndexCache cache;
-    JoinTiming tm;
-    float ms_ext = 0, ms_chain = 0, ms_gapped = 0;
-    hipStream_t st = stream();
+    float ms_chain = 0, ms_gapped = 0;
     int rc = 0;
-    uint64_t pos = 0;
-    // units accumulate into a batch; a full batch is handed to the worker (K5/K6) while the next one
-    // is being filled.  Four batches per call (at most MAX_GROUPS units each).
-    uint64_t nunits = 0;
-    for (int m = 0; m < 2; m++) if (p->strand & (m ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS)) nunits += npairs;
-    const size_t MAX_GROUPS = 8192;
-    const size_t batch_groups = g_overlap ? std::max<size_t>(8, std::min<size_t>(MAX_GROUPS, (nunits + 3) / 4)) : MAX_GROUPS;
-    Batch cur;
-    cur.buf = 0;
-    std::future<BatchResult> pending[2];
-    auto collect = [&](int buf) -> int {  // wait for the batch that used buffer `buf`
-        if (!pending[buf].valid()) return 0;
-        BatchResult r = pending[buf].get();
+    const size_t MAX_GROUPS = 8192;  // units per K5/K6 batch
+    HIP_TRY(hipStreamSynchronize(stream()));
+    for (size_t b0 = 0; b0 < units.size() && !rc; b0 += MAX_GROUPS) {
+        size_t b1 = std::min(units.size(), b0 + MAX_GROUPS);
+        Batch batch;
+        batch.groups.resize(b1 - b0);
+        batch.group_pair.resize(b1 - b0);
+        Shared sh;
+        sh.A = A; sh.QG = QG; sh.p = p; sh.units = &units; sh.begin = b0; sh.end = b1; sh.next = b0;
+        sh.cache = &cache; sh.batch = &batch;
+        std::vector<std::thread> th;
+        for (int l = 1; l < nlanes; l++) th.emplace_back(lane_main, &g_lane[l], &sh);
+        lane_main(&g_lane[0], &sh);  // the calling thread is lane 0
+        for (auto &t : th) t.join();
+        if (sh.rc.load()) { rc = sh.rc.load(); set_error(sh.err); break; }
+        BatchResult r = run_batch(batch, p, &per_pair);
         g_stats.chained_hsps += r.chained;
         ms_chain += r.ms_chain;
         ms_gapped += r.ms_gapped;
-        if (r.rc) { set_error(r.err); return r.rc; }
-        return 0;
-    };
-    auto flush = [&]() -> int {
-        HIP_TRY(hipStreamSynchronize(st));  // the batch's HSP copies are complete
-        int buf = cur.buf;
-        // one worker at a time (they share the K5/K6 work buffers); this also frees the other HSP
-        // buffer, which is the one refilled next
-        int prc = collect(buf ^ 1);
-        if (prc) return prc;
-        pending[buf] = std::async(g_overlap ? std::launch::async : std::launch::deferred, run_batch, std::move(cur), p, &per_pair);
-        if (!g_overlap) { int r0 = collect(buf); if (r0) return r0; }
-        cur = Batch();
-        cur.buf = buf ^ 1;
-        return 0;
-    };
-    while (pos < npairs && !rc) {
-        uint32_t tid = pair_t[ord[pos]];
-        uint64_t end = pos;
-        while (end < npairs && pair_t[ord[end]] == tid) end++;
-        const Scaffold &ts = A->scaf[tid];
-        IndexView ti;
-        StrandView tv;
-        if ((rc = cache.get(ts, 0, true, &ti, &tv))) break;
-        for (uint64_t k = pos; k < end && !rc; k++) {
-            uint32_t qid = pair_q[ord[k]];
-            const Scaffold &qs = QG->scaf[qid];
-            for (int minus = 0; minus < 2 && !rc; minus++) {
-                if (!(p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))) continue;
-                IndexView qi;
-                StrandView qv;
-                if ((rc = cache.get(qs, minus, false, &qi, &qv))) break;
-                uint64_t nhits = 0, nh = 0;
-                if ((rc = join_hits(ti, qi, p->transitions, g_hits, &nhits, &tm))) break;
-                if ((rc = ungapped_hsps_device(tv, qv, (const uint2 *)g_hits.p, nhits, p, g_unit_hsps, &nh, &ms_ext))) break;
-                // append this unit's HSPs to the batch-level array
-                DeviceBuf &hb = g_hsp_batch[cur.buf];
-                if ((cur.nh_total + nh) * sizeof(mimeo_hsp) > hb.cap) {
-                    DeviceBuf bigger;
-                    if ((rc = bigger.reserve((cur.nh_total + nh) * 2 * sizeof(mimeo_hsp) + 4096))) break;
-                    if (cur.nh_total) HIP_TRY(hipMemcpyAsync(bigger.p, hb.p, cur.nh_total * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    hb.release();
-                    hb = bigger;
-                }
-                if (nh) HIP_TRY(hipMemcpyAsync((char *)hb.p + cur.nh_total * sizeof(mimeo_hsp), g_unit_hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToDevice, st));
-                Group g;
-                memset(&g, 0, sizeof g);
-                g.T = tv; g.Q = qv; g.tid = tid; g.qid = qid; g.minus = (uint32_t)minus;
-                g.hsp_begin = cur.nh_total; g.hsp_end = cur.nh_total + nh;
-                cur.groups.push_back(g);
-                cur.group_pair.push_back(ord[k]);
-                cur.nh_total += nh;
-                g_stats.pair_strands++;
-                g_stats.seed_hits += nhits;
-                g_stats.hsps += nh;
-                g_stats.query_bases_scanned += qs.len;
-                g_stats.scan_bytes_algorithmic += scan_bytes_algorithmic(qs.len, nhits);
-                g_stats.scan_bytes_kernel += scan_bytes_kernel(ti.n, qi.n, nhits);
-                g_stats.scan_launches++;
-                if (cur.groups.size() >= batch_groups) rc = flush();
-            }
-        }
-        pos = end;
+        if (r.rc) { rc = r.rc; set_error(r.err); }
     }
-    if (!rc && !cur.groups.empty()) rc = flush();
-    for (int b = 0; b < 2; b++) { int r2 = collect(b); if (!rc) rc = r2; }
     cache.clear();
     if (rc) return rc;
     uint64_t total = 0;
@@ -234,9 +289,11 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     *nout = total;
     g_stats.alignments = total;
     g_stats.ms_index = cache.ms;
-    g_stats.ms_scan = tm.ms_count + tm.ms_fill;
-    g_stats.ms_scan_fill = tm.ms_fill;
-    g_stats.ms_extend = ms_ext;
+    for (int l = 0; l < nlanes; l++) {
+        g_stats.ms_scan += g_lane[l].tm.ms_count + g_lane[l].tm.ms_fill;
+        g_stats.ms_scan_fill += g_lane[l].tm.ms_fill;
+        g_stats.ms_extend += g_lane[l].ms_ext;
+    }
     g_stats.ms_chain = ms_chain;
     g_stats.ms_gapped = ms_gapped;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -2,6 +2,7 @@
 (src/mimeo/wrappers.py:899-1271, src/mimeo/utils.py:213-254) become once the shell pipeline
 is replaced by calls through the C-ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -50,6 +51,29 @@ class Genome:
         h = C.c_void_p()
         _ffi.check(lib.mimeo_genome_create(len(arrs), bases.ctypes.data, offsets.ctypes.data, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_fasta(cls, paths, split_dir=None):
+        """Stream FASTA file(s) from disk straight into device memory (native parser thread + K1;
+        replaces utils.py:274-309 splitFasta and the Biopython parses).  `split_dir`: also leave one
+        `<id>.fa` per record there, like the reference's --adir/--bdir."""
+        lib = _ffi.load()
+        paths = [paths] if isinstance(paths, (str, bytes)) else list(paths)
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = C.c_void_p()
+        _ffi.check(lib.mimeo_genome_load_fasta(arr, len(paths), os.fsencode(split_dir) if split_dir else None, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h = h
+        n = C.c_uint32()
+        _ffi.check(lib.mimeo_genome_nscaf(h, C.byref(n)))
+        self.names, self.lengths = [], []
+        for i in range(n.value):
+            nm, ln = C.c_char_p(), C.c_uint64()
+            _ffi.check(lib.mimeo_genome_name(h, i, C.byref(nm)))
+            _ffi.check(lib.mimeo_genome_length(h, i, C.byref(ln)))
+            self.names.append(nm.value.decode())
+            self.lengths.append(int(ln.value))
+        return self
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:

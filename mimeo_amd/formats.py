@@ -50,8 +50,9 @@ def check_unique(names):
 
 
 def chromlens(names, seqs, outfile=None):
-    """utils.py:502-557: (id, str(len)) sorted by id; optional `id\\tlen` file (bedtools -g)."""
-    lens = sorted(((n, str(len(s))) for n, s in zip(names, seqs)), key=lambda x: x[0])
+    """utils.py:502-557: (id, str(len)) sorted by id; optional `id\\tlen` file (bedtools -g).
+    `seqs`: sequences or plain lengths."""
+    lens = sorted(((n, str(s if isinstance(s, int) else len(s))) for n, s in zip(names, seqs)), key=lambda x: x[0])
     if outfile:
         with open(outfile, 'w') as f:
             for n, l in lens:

@@ -64,9 +64,8 @@ def general_rows(alns, tnames, qnames):
 def main(argv=None):
     files, opt = parse(sys.argv[1:] if argv is None else argv)
     engine.init(0)
-    tn, ts = formats.read_fasta(files[0])
-    qn, qs = formats.read_fasta(files[1])
-    T, Q = engine.Genome(tn, ts), engine.Genome(qn, qs)
+    T, Q = engine.Genome.from_fasta(files[0]), engine.Genome.from_fasta(files[1])
+    tn, qn = T.names, Q.names
     p = engine.default_params(hspthresh=opt['hspthresh'], entropy=opt['entropy'], chain=opt['chain'], gapped=opt['gapped'],
                               strand={'both': 3, 'plus': 1, 'minus': 2}[opt['strand']])
     alns = engine.align_pairs(T, Q, [(t, q) for t in range(len(tn)) for q in range(len(qn))], p)

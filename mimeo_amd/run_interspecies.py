@@ -22,14 +22,13 @@ def main(argv=None):
     args = mainArgs(argv)
     dist, outdir = _cli.start(args)
     logging.info('Starting cross-species repeat identification...')
-    an, aseq = _cli.load_genome(args.afasta, args.adir, 'A')
-    bn, bseq = _cli.load_genome(args.bfasta, args.bdir, 'B')
+    A = _cli.load_genome(args.afasta, args.adir, 'A')
+    B = _cli.load_genome(args.bfasta, args.bdir, 'B')
     outtab = os.path.join(outdir, args.outfile)
     gffout = os.path.join(outdir, args.gffout)
     if dist.rank == 0:
-        formats.chromlens(an, aseq, os.path.join(outdir, 'A_gen_lens.txt'))
-    A, B = engine.Genome(an, aseq), engine.Genome(bn, bseq)
-    pairs = workflow.all_pairs(len(an), len(bn))
+        formats.chromlens(A.names, A.lengths, os.path.join(outdir, 'A_gen_lens.txt'))
+    pairs = workflow.all_pairs(len(A.names), len(B.names))
     logging.info('Running alignments...')
     workflow.self_repeats(A, pairs, outtab, gffout, minIdt=args.minIdt, minLen=args.minLen, hspthresh=3000,
                           minCov=args.minCov, reuseTab=args.recycle, label=args.label, prefix=args.prefix, dist=dist,

@@ -26,12 +26,11 @@ def main(argv=None):
     args = mainArgs(argv)
     dist, outdir = _cli.start(args)
     logging.info('Starting genome mapping workflow.')
-    an, aseq = _cli.load_genome(args.afasta, args.adir, 'A')
-    bn, bseq = _cli.load_genome(args.bfasta, args.bdir, 'B')
+    A = _cli.load_genome(args.afasta, args.adir, 'A')
+    B = _cli.load_genome(args.bfasta, args.bdir, 'B')
     outtab = os.path.join(outdir, args.outfile)
-    chrLens = formats.chromlens(an, aseq)  # run_map.py:255 (no file)
-    A, B = engine.Genome(an, aseq), engine.Genome(bn, bseq)
-    pairs = workflow.all_pairs(len(an), len(bn))
+    chrLens = formats.chromlens(A.names, A.lengths)  # run_map.py:255 (no file)
+    pairs = workflow.all_pairs(len(A.names), len(B.names))
     if not pairs:
         logging.error('No files to align. Check --adir and --bdir contain at least one fasta each.')
         sys.exit(1)

@@ -24,13 +24,12 @@ def main(argv=None):
     args = mainArgs(argv)
     dist, outdir = _cli.start(args)
     logging.info('Starting self-alignment workflow.')
-    names, seqs = _cli.load_genome(args.afasta, args.adir, 'A')
+    A = _cli.load_genome(args.afasta, args.adir, 'A')
     outtab = os.path.join(outdir, args.outfile)
     gffout = os.path.join(outdir, args.gffout)
     if dist.rank == 0:
-        formats.chromlens(names, seqs, os.path.join(outdir, 'A_gen_lens.txt'))  # run_self.py:223-224
-    A = engine.Genome(names, seqs)
-    pairs = workflow.all_pairs(len(names))
+        formats.chromlens(A.names, A.lengths, os.path.join(outdir, 'A_gen_lens.txt'))  # run_self.py:223-224
+    pairs = workflow.all_pairs(len(A.names))
     logging.info('Running alignments...')
     workflow.self_repeats(A, pairs, outtab, gffout, minIdt=args.minIdt, minLen=args.minLen, hspthresh=args.hspthresh,
                           minCov=args.minCov, intraCov=args.intraCov, splitSelf=args.strictSelf, reuseTab=args.recycle,

@@ -40,9 +40,11 @@ def _mutate(rng, cons, div, indel_rate):
 
 
 def synth_genome(seed, total_bp, nscaf, repeat_frac=0.05, families=40, max_div=0.15,
-                 indel_rate=0.005, cons_len=(300, 6000), prefix='scaf', shared_families=None):
+                 indel_rate=0.005, cons_len=(300, 6000), prefix='scaf', shared_families=None, microsat_frac=0.0):
     """Return (names, [uint8 ASCII arrays]).  ``shared_families`` lets two genomes (mimeo x)
-    carry copies of the same consensus set: pass the list returned by ``make_families``."""
+    carry copies of the same consensus set: pass the list returned by ``make_families``.
+    ``microsat_frac`` (C5: 0.01) overwrites that share of the genome with perfect microsatellites
+    of period 1-6 and length 50-500 bp."""
     rng = np.random.Generator(np.random.PCG64(seed))
     L = total_bp // nscaf
     codes = [rng.integers(0, 4, size=L, dtype=np.uint8) for _ in range(nscaf)]
@@ -67,6 +69,16 @@ def synth_genome(seed, total_bp, nscaf, repeat_frac=0.05, families=40, max_div=0
         occ[s][a:b] = True
         codes[s][p:p + cp.size] = cp
         covered += cp.size
+    target, covered = int(microsat_frac * L * nscaf), 0
+    while covered < target:
+        period, ln = int(rng.integers(1, 7)), int(rng.integers(50, 501))
+        unit = rng.integers(0, 4, size=period, dtype=np.uint8)
+        if period > 1 and (unit == unit[0]).all():
+            unit[-1] = (unit[0] + 1) & 3
+        s, p = int(rng.integers(0, nscaf)), int(rng.integers(0, max(1, L - ln)))
+        ln = min(ln, L - p)
+        codes[s][p:p + ln] = np.resize(unit, ln)
+        covered += ln
     names = ['%s%04d' % (prefix, i) for i in range(nscaf)]
     return names, [_ACGT[c] for c in codes]
 

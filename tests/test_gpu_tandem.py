@@ -87,3 +87,24 @@ def test_trf_filter_and_writetrf(eng, tmp_path):
     lines = open(out).read().split('\n')
     assert lines[0].startswith('#name1\tstrand1') and lines[1].split('\t')[2] == '20000' and out.endswith('.tab.trf')
     g.close()
+
+
+def test_filter_command_drops_ssr_rich_records(eng, tmp_path):
+    """`mimeo filter` (run_filter.py:127-210 / wrappers.py:265-377): a library record stays when less than
+    maxtandem percent of it is tandem (or N); survivors are written in input order."""
+    from mimeo_amd import formats, run_filter
+    rng = np.random.default_rng(5)
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), n))
+    recs = [('te1', rnd(900)),
+            ('ssr_ca', b'CA' * 300),
+            ('half', rnd(600) + b'AAG' * 190),           # ~49 % tandem
+            ('mostlyN', rnd(300) + b'N' * 400),
+            ('te2', rnd(2000) + b'AT' * 30)]            # 3 % tandem
+    lib = tmp_path / 'lib.fa'
+    lib.write_bytes(b''.join(b'>' + n.encode() + b' desc\n' + s + b'\n' for n, s in recs))
+    run_filter.main(['--infile', str(lib), '-d', str(tmp_path / 'out')])
+    names, seqs = formats.read_fasta(str(tmp_path / 'out' / 'lib_filtered.fa'))
+    assert names == ['te1', 'te2']
+    assert seqs[0].tobytes() == recs[0][1] and seqs[1].tobytes() == recs[4][1]
+    keep = run_filter.filter_fasta(str(lib), str(tmp_path / 'o2.fa'), maxtandem=60)
+    assert keep == ['te1', 'half', 'mostlyN', 'te2']
