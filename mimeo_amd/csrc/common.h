@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -122,8 +123,32 @@ struct JoinCtx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void release();
 };
+// Lets one kernel run alone on the device while several lanes (streams) are active: begin() makes
+// `mine` wait for everything the other streams have been given so far, end() makes the other
+// streams wait for what `mine` was given in between.  Used for the bandwidth-bound seed-scan fill.
+struct Exclusive {
+    std::mutex mu;
+    int n = 0;
+    hipStream_t st[8];
+    hipEvent_t reached[8], done[8];
+    int index_of(hipStream_t s) const { for (int i = 0; i < n; i++) if (st[i] == s) return i; return -1; }
+    void begin(hipStream_t mine) {
+        mu.lock();
+        for (int i = 0; i < n; i++)
+            if (st[i] != mine) { (void)hipEventRecord(reached[i], st[i]); (void)hipStreamWaitEvent(mine, reached[i], 0); }
+    }
+    void end(hipStream_t mine) {
+        int me = index_of(mine);
+        if (me >= 0) {
+            (void)hipEventRecord(done[me], mine);
+            for (int i = 0; i < n; i++)
+                if (st[i] != mine) (void)hipStreamWaitEvent(st[i], done[me], 0);
+        }
+        mu.unlock();
+    }
+};
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm);
+              JoinTiming *tm, Exclusive *ex = nullptr);
 
 // K4: seed hits -> HSPs (k4_extend.hip); out_hsps holds mimeo_hsp records on the device
 struct ExtCounters;

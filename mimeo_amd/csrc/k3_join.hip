@@ -198,7 +198,7 @@ void JoinCtx::release() {
 }
 
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm) {
+              JoinTiming *tm, Exclusive *ex) {
     if (!ctx.tile_count) {
         HIP_TRY(hipMalloc((void **)&ctx.tile_count, (NTILE + 2) * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&ctx.tile_base, (NTILE + 2) * sizeof(unsigned long long)));
@@ -222,11 +222,15 @@ int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transiti
     }
     int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(g_ev[2], st));
+    if (ex) ex->begin(st);
+    hipError_t e2 = hipEventRecord(g_ev[2], st);
     if (total)
         hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(FILL_THREADS), 0, st, T.off, T.pos, Q.off, Q.pos, transitions,
                            g_tile_base, (uint2 *)hits.p);
-    HIP_TRY(hipEventRecord(g_ev[3], st));
+    hipError_t e3 = hipEventRecord(g_ev[3], st);
+    if (ex) ex->end(st);
+    HIP_TRY(e2);
+    HIP_TRY(e3);
     HIP_TRY(hipGetLastError());
     if (tm) {
         HIP_TRY(hipEventSynchronize(g_ev[3]));

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, S
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                               uint64_t cand_cap, uint64_t *__restrict__ fkey,
                                                               uint32_t *__restrict__ fprev,
-                                                              uint2 *__restrict__ longq) {
+                                                              uint2 *__restrict__ longq, int skip_diag0) {
     __shared__ uint32_t tab[GROUP_TAB];
     for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
     __syncthreads();
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, S
     for (uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x; gid < nhits;
          gid += (uint64_t)gridDim.x * EXT_THREADS) {
         const uint2 h = hits[gid];
+        if (skip_diag0 && h.x == h.y) continue;
         const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
         const int32_t d = (int32_t)h.x - (int32_t)h.y;
         // ---- left walk, with detection of an earlier seed hit at every reached boundary
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                               uint64_t cand_cap, uint64_t *__restrict__ fkey,
                                                               uint32_t *__restrict__ fprev,
-                                                              uint2 *__restrict__ medq) {
+                                                              uint2 *__restrict__ medq, int skip_diag0) {
     __shared__ uint32_t tab[GROUP_TAB];
     // per-wave staging of the three output queues: one global atomic per >= 64 records instead of
     // one per wavefront iteration (same-address atomics serialise at ~15 ns each)
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         uint64_t r_fk = 0;
         uint32_t r_fp = 0;
         Cand r_cd{0, 0, 0, 0};
-        if (gid < nhits) {
-        h = hits[gid];
+        if (gid < nhits) h = hits[gid];
+        if (gid < nhits && !(skip_diag0 && h.x == h.y)) {  // the main diagonal of a self unit belongs to k4_diag0
         const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
         const int32_t d = (int32_t)h.x - (int32_t)h.y;
         const uint32_t bt = h.x & 31u, bq = h.y & 31u, sh = (bq - bt) & 31u;
@@ -490,14 +491,14 @@ __device__ WalkResult wave_walk(const StrandView &T, const StrandView &Q, int32_
     return r;
 }
 
-// Word-granular walk without seed detection: 64 lanes x 4 words x 32 bases = 8192 bases per step.
+// Word-granular walk without seed detection: 64 lanes x 8 words x 32 bases = 16384 bases per step.
 // Each lane reduces its 128 bases to (sum S, best prefix M and its position, lowest prefix mn,
 // deepest drop a below the running in-lane maximum); a wave prefix sum / prefix max turns these
 // into the exact running score and best at every lane boundary, and the walk can only stop inside
 // the first lane with  a < -xdrop  or  run_in + mn < best_in - xdrop, which then replays its
 // bases one by one.  Words that are all matches (the common case on long diagonals) need no
 // per-base loop at all.
-constexpr int WALK_WORDS = 4;
+constexpr int WALK_WORDS = 8;
 
 __device__ WalkResult wave_walk_fast(const StrandView &T, const StrandView &Q, int32_t et, int32_t d, int dir,
                                      uint32_t maxsteps, int xdrop) {
@@ -756,6 +757,42 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(StrandView T,
     }
 }
 
+// ---- K4e: the main diagonal of a strand aligned to itself -------------------------------------
+// When target and query are the same strand every valid seed position is a hit on diagonal 0
+// (millions of followers of one head).  K4a leaves those hits alone and this kernel replays the
+// sequential rule directly on the seed-validity planes with one wavefront: extend the first seed,
+// skip every seed whose end lies inside the reach, extend the next one, ...
+__global__ __launch_bounds__(64) void k4_diag0(StrandView T, StrandView Q, int xdrop, int hspthresh, int transitions,
+                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand, uint64_t cand_cap) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwords = (T.len + 31u) >> 5;
+    uint32_t p = 0;  // first seed start still to be considered
+    for (;;) {
+        uint32_t found = 0xFFFFFFFFu;
+        for (uint32_t w0 = p >> 5; w0 < nwords; w0 += 64u) {
+            const uint32_t w = w0 + lane;
+            uint32_t m = 0;
+            if (w < nwords) {
+                m = (T.svt ? T.svt[w] : T.pw[w].w) & Q.pw[w].w;
+                if (w == (p >> 5)) m &= 0xFFFFFFFFu << (p & 31u);
+            }
+            const uint64_t b = __ballot(m != 0);
+            if (b) {
+                const int l = __builtin_ctzll(b);
+                const uint32_t mm = (uint32_t)__shfl((int)m, l);
+                found = ((w0 + (uint32_t)l) << 5) + (uint32_t)__builtin_ctz(mm);
+                break;
+            }
+        }
+        if (found == 0xFFFFFFFFu) break;
+        uint32_t rext = 0;
+        wave_extend_emit(T, Q, make_uint2(found, found), xdrop, hspthresh, transitions, false, ctr, cand, cand_cap, nullptr,
+                         nullptr, &rext);
+        const uint32_t reach = found + SEED_LEN + rext;  // a later seed is extended iff its end lies beyond
+        p = max(found + 1u, reach - (uint32_t)(SEED_LEN - 1));
+    }
+}
+
 // ---- K4d: entropy adjustment + threshold, one wavefront per candidate --------------------
 __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandView Q, const Cand *__restrict__ cand,
                                                           uint64_t cand_cap, int hspthresh, int entropy,
@@ -768,17 +805,31 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
     if (entropy) {
         uint32_t cnt[4] = {0, 0, 0, 0};
         int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
-        for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 64u * 32u) {
-            int32_t pt = (int32_t)(c.tstart + w0), pq = pt - d;
-            const Win32 tw = win32(T, pt), qw = win32(Q, pq);
-            const uint32_t tlo = tw.lo, thi = tw.hi;
-            uint32_t m = ~((tlo ^ qw.lo) | (thi ^ qw.hi)) & ~(tw.nm | qw.nm);
-            uint32_t rem = c.len - w0;
-            if (rem < 32) m &= (1u << rem) - 1u;
-            cnt[0] += __popc(m & ~tlo & ~thi);
-            cnt[1] += __popc(m & tlo & ~thi);
-            cnt[2] += __popc(m & ~tlo & thi);
-            cnt[3] += __popc(m & tlo & thi);
+        // four independent windows per iteration: the loads of a long HSP overlap instead of queueing
+        for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 4u * 64u * 32u) {
+            Win32 tw[4], qw[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t o = w0 + (uint32_t)j * 64u * 32u;
+                if (o < c.len) {
+                    const int32_t pt = (int32_t)(c.tstart + o);
+                    tw[j] = win32(T, pt);
+                    qw[j] = win32(Q, pt - d);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t o = w0 + (uint32_t)j * 64u * 32u;
+                if (o >= c.len) break;
+                const uint32_t tlo = tw[j].lo, thi = tw[j].hi;
+                uint32_t m = ~((tlo ^ qw[j].lo) | (thi ^ qw[j].hi)) & ~(tw[j].nm | qw[j].nm);
+                const uint32_t rem = c.len - o;
+                if (rem < 32) m &= (1u << rem) - 1u;
+                cnt[0] += __popc(m & ~tlo & ~thi);
+                cnt[1] += __popc(m & tlo & ~thi);
+                cnt[2] += __popc(m & ~tlo & thi);
+                cnt[3] += __popc(m & tlo & thi);
+            }
         }
         for (int b = 0; b < 4; b++)
             for (int o = 32; o > 0; o >>= 1) cnt[b] += __shfl_xor(cnt[b], o);
@@ -855,15 +906,17 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         HIP_TRY(hipMemsetAsync(W.nsel.p, 0, 16, st));
         uint64_t nb = (nhits + FAST_THREADS - 1) / FAST_THREADS;
         if (nb > 256 * 16) nb = 256 * 16;  // grid-stride: the LDS table is loaded once per workgroup
+        // target and query are the same strand of the same scaffold: diagonal 0 is handled by k4_diag0
+        const int same_strand = (T.pw == Q.pw && T.len == Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1 : 0;
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
                            p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
-                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p)
+                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand)
         if (variant == 0)
             hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits,
                                (const unsigned long long *)nullptr, p->xdrop, p->hspthresh, p->transitions,
                                (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
-                               (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+                               (uint32_t *)W.fprev.p, (uint2 *)W.longq.p, same_strand);
         else if (variant == 2) K4_LAUNCH(2);
         else if (variant == 3) K4_LAUNCH(3);
         else K4_LAUNCH(1);
@@ -872,7 +925,10 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         hipLaunchKernelGGL(k4_extend_generic, dim3(2048), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.medq.p,
                            (uint64_t)0, (const unsigned long long *)&W.ctr->nmed, p->xdrop, p->hspthresh, p->transitions,
                            (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
-                           (uint32_t *)W.fprev.p, (uint2 *)W.longq.p);
+                           (uint32_t *)W.fprev.p, (uint2 *)W.longq.p, 0);
+        if (same_strand)
+            hipLaunchKernelGGL(k4_diag0, dim3(1), dim3(64), 0, st, T, Q, p->xdrop, p->hspthresh, p->transitions, W.ctr,
+                               (Cand *)W.cand.p, cand_cap);
         hipLaunchKernelGGL(k4_extend_long, dim3(64), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.longq.p, p->xdrop,
                            p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                            (uint32_t *)W.fprev.p);

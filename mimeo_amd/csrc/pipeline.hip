@@ -160,6 +160,7 @@ struct Shared {
     std::mutex mu;                // batch append, stats, err
     IndexCache *cache;
     HeavyGate gate;
+    Exclusive *excl;
     Batch *batch;
 };
 
@@ -185,7 +186,7 @@ static void lane_main(Lane *ln, Shared *sh) {
         bool held = true;
         sh->gate.acquire(st);
         std::function<void()> after_fast = [&] { if (held) { sh->gate.release(st, ln->heavy_end); held = false; } };
-        rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm);
+        rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm, sh->excl);
         if (!rc) rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, nhits, p, ln->unit_hsps, &nh, &ln->ms_ext, &after_fast);
         after_fast();  // no hits, or an error before the fast kernel
         if (rc) { fail(rc); break; }
@@ -242,6 +243,20 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         g_lane[l].tm = JoinTiming();
         g_lane[l].ms_ext = 0;
     }
+    static Exclusive excl;  // events are created once; the lane set may change between calls
+    {
+        static bool ev_ok = false;
+        if (!ev_ok) {
+            for (int i = 0; i < 8; i++) {
+                HIP_TRY(hipEventCreateWithFlags(&excl.reached[i], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&excl.done[i], hipEventDisableTiming));
+            }
+            ev_ok = true;
+        }
+        excl.n = nlanes;
+        for (int l = 0; l < nlanes; l++) excl.st[l] = g_lane[l].st;
+    }
+    const bool use_excl = nlanes > 1 && !(getenv("MIMEO_NO_EXCL") && atoi(getenv("MIMEO_NO_EXCL")));
     // units in target-major order (stable in the caller's pair order): neighbouring units share the
     // target index, and the two lanes work on neighbouring units
     std::vector<uint64_t> ord(npairs);
@@ -265,7 +280,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         batch.group_pair.resize(b1 - b0);
         Shared sh;
         sh.A = A; sh.QG = QG; sh.p = p; sh.units = &units; sh.begin = b0; sh.end = b1; sh.next = b0;
-        sh.cache = &cache; sh.batch = &batch;
+        sh.cache = &cache; sh.batch = &batch; sh.excl = use_excl ? &excl : nullptr;
         std::vector<std::thread> th;
         for (int l = 1; l < nlanes; l++) th.emplace_back(lane_main, &g_lane[l], &sh);
         lane_main(&g_lane[0], &sh);  // the calling thread is lane 0
