@@ -62,7 +62,7 @@ __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandVie
 // group", and otherwise the group is applied in one step.  Groups holding an N, an earlier seed
 // hit, or the sequence end fall back to single bases.
 constexpr int GROUP_TAB = 4096;
-constexpr int QCAP = 128;  // per-wave staging capacity of the K4a output queues
+constexpr int QCAP = 64;  // per-wave staging capacity of the K4a output queues (= the most one iteration adds)
 constexpr int FAST_THREADS = 512;  // K4a fast kernel: 8 wavefronts share one copy of the group table
 
 static inline int host_sub(int dl, int dh, int cg) {
@@ -373,47 +373,77 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         }  // right walk
         }  // VARIANT != 2
         }  // gid < nhits
-        // ---- stage the records; flush a queue with one atomic once it holds >= 64
+        // ---- stage the records; a queue is flushed with one atomic when the new records would not fit
+        // (QCAP = 64 = the most one iteration can add), and at the end
+        const bool last = g0 + stride >= nhits;
         uint64_t m = __ballot(q_med);
-        if (m) {
+        if (m || (last && n_med)) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_med + add > (uint32_t)QCAP) {
+                __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
+                b = __shfl(b, 0);
+                if (lane < n_med) medq[b + lane] = s_med[wv][lane];
+                n_med = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
             if (q_med) s_med[wv][n_med + __popcll(m & lt_mask)] = h;
-            n_med += __popcll(m);
+            n_med += add;
+            if (last && n_med) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
+                b = __shfl(b, 0);
+                if (lane < n_med) medq[b + lane] = s_med[wv][lane];
+                n_med = 0;
+            }
         }
         m = __ballot(q_fol);
-        if (m) {
-            if (q_fol) { uint32_t i = n_fol + __popcll(m & lt_mask); s_fk[wv][i] = r_fk; s_fp[wv][i] = r_fp; }
-            n_fol += __popcll(m);
+        if (m || (last && n_fol)) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_fol + add > (uint32_t)QCAP) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
+                b = __shfl(b, 0);
+                if (lane < n_fol) { fkey[b + lane] = s_fk[wv][lane]; fprev[b + lane] = s_fp[wv][lane]; }
+                n_fol = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (q_fol) { const uint32_t i = n_fol + __popcll(m & lt_mask); s_fk[wv][i] = r_fk; s_fp[wv][i] = r_fp; }
+            n_fol += add;
+            if (last && n_fol) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
+                b = __shfl(b, 0);
+                if (lane < n_fol) { fkey[b + lane] = s_fk[wv][lane]; fprev[b + lane] = s_fp[wv][lane]; }
+                n_fol = 0;
+            }
         }
         m = __ballot(q_cd);
-        if (m) {
+        if (m || (last && n_cd)) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_cd + add > (uint32_t)QCAP) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
+                b = __shfl(b, 0);
+                if (lane < n_cd && b + lane < cand_cap) cand[b + lane] = s_cd[wv][lane];
+                n_cd = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
             if (q_cd) s_cd[wv][n_cd + __popcll(m & lt_mask)] = r_cd;
-            n_cd += __popcll(m);
-        }
-        const bool last = g0 + stride >= nhits;
-        if (n_med >= 64 || (last && n_med)) {
-            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
-            b = __shfl(b, 0);
-            for (uint32_t i = lane; i < n_med; i += 64) medq[b + i] = s_med[wv][i];
-            n_med = 0;
-        }
-        if (n_fol >= 64 || (last && n_fol)) {
-            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
-            b = __shfl(b, 0);
-            for (uint32_t i = lane; i < n_fol; i += 64) { fkey[b + i] = s_fk[wv][i]; fprev[b + i] = s_fp[wv][i]; }
-            n_fol = 0;
-        }
-        if (n_cd >= 64 || (last && n_cd)) {
-            __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
-            b = __shfl(b, 0);
-            for (uint32_t i = lane; i < n_cd; i += 64)
-                if (b + i < cand_cap) cand[b + i] = s_cd[wv][i];
-            n_cd = 0;
+            n_cd += add;
+            if (last && n_cd) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
+                b = __shfl(b, 0);
+                if (lane < n_cd && b + lane < cand_cap) cand[b + lane] = s_cd[wv][lane];
+                n_cd = 0;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
