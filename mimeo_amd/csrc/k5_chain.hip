@@ -3,15 +3,19 @@
 // Work unit = one group = one (target scaffold, query scaffold, strand); one workgroup owns it:
 //   * rank-sort the group's HSPs by (tstart, qstart, length);
 //   * chain DP  best[j] = score[j] + max(0, max{best[i] : i ends at or before the start of j in both
-//     sequences}), evaluated forward (when j is final every later compatible k is relaxed), ties
-//     to the earliest predecessor and the earliest chain end;
+//     sequences}), evaluated forward in tiles of 64: one wavefront finalises a tile (lane = HSP,
+//     64 shuffle steps), then the whole workgroup relaxes every later HSP against the tile's 64
+//     final values from LDS.  Tiles and the members of a tile are visited in ascending order and
+//     only a strict improvement replaces a predecessor, so ties go to the earliest predecessor
+//     and the earliest chain end;
 //   * flag the chain and order the chained HSPs by (score desc, tstart, qstart, length) — the
 //     order in which K6 turns them into anchors.
 #include "device_util.h"
 
 namespace mimeo {
 
-constexpr int CH_THREADS = 256;
+constexpr int CH_THREADS = 1024;
+constexpr int CH_TILE = 64;  // HSPs finalised per step of the chain DP (one wavefront)
 
 __device__ __forceinline__ bool hsp_less(const mimeo_hsp &a, const mimeo_hsp &b) {
     if (a.tstart != b.tstart) return a.tstart < b.tstart;
@@ -35,6 +39,8 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
     __shared__ long long s_best[CH_THREADS / 64];
     __shared__ uint32_t s_idx[CH_THREADS / 64];
     __shared__ uint32_t s_m;
+    __shared__ uint32_t s_te[CH_TILE], s_qe[CH_TILE];
+    __shared__ long long s_b[CH_TILE];
     if (n == 0) { if (tid == 0) G.nchain = 0; return; }
     // 1. rank sort into hs[b0 .. b0+n)
     for (uint32_t i = tid; i < n; i += CH_THREADS) {
@@ -51,16 +57,41 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
     if (do_chain) {
         for (uint32_t k = tid; k < n; k += CH_THREADS) { cand[b0 + k] = 0; pred[b0 + k] = -1; }
         __syncthreads();
-        for (uint32_t j = 0; j < n; j++) {
-            mimeo_hsp hj = hs[b0 + j];
-            long long bj = cand[b0 + j] + hj.score;
-            if (tid == 0) best[b0 + j] = bj;
-            uint32_t te = hj.tstart + hj.length, qe = hj.qstart + hj.length;
-            // relax every later HSP that starts after hj ends (strict improvement keeps the earliest j)
-            uint32_t k0 = j + 1 + ((tid + CH_THREADS - ((j + 1) % CH_THREADS)) % CH_THREADS);
-            for (uint32_t k = k0; k < n; k += CH_THREADS) {
+        for (uint32_t t0 = 0; t0 < n; t0 += CH_TILE) {
+            // a. wavefront 0 finalises HSPs t0 .. t0+63: every earlier tile has already relaxed them
+            if (tid < CH_TILE) {
+                const uint32_t j = t0 + tid;
+                const bool live = j < n;
+                mimeo_hsp hj;
+                hj.tstart = hj.qstart = 0xFFFFFFFFu; hj.length = 0; hj.score = 0;
+                long long cj = 0;
+                int pj = -1;
+                if (live) { hj = hs[b0 + j]; cj = cand[b0 + j]; pj = pred[b0 + j]; }
+                const uint32_t te = hj.tstart + hj.length, qe = hj.qstart + hj.length;
+                const uint32_t cnt = min((uint32_t)CH_TILE, n - t0);
+                for (uint32_t jj = 0; jj + 1 < cnt; jj++) {
+                    const long long bj = __shfl(cj + hj.score, (int)jj);  // final: members before jj are done
+                    const uint32_t tej = (uint32_t)__shfl((int)te, (int)jj), qej = (uint32_t)__shfl((int)qe, (int)jj);
+                    if (live && tid > jj && tej <= hj.tstart && qej <= hj.qstart && bj > cj) { cj = bj; pj = (int)(t0 + jj); }
+                }
+                if (live) {
+                    const long long bj = cj + hj.score;
+                    best[b0 + j] = bj;
+                    pred[b0 + j] = pj;
+                    s_te[tid] = te; s_qe[tid] = qe; s_b[tid] = bj;
+                }
+            }
+            __syncthreads();
+            // b. everybody relaxes the HSPs behind the tile against its final values
+            const uint32_t cnt = min((uint32_t)CH_TILE, n - t0);
+            for (uint32_t k = t0 + CH_TILE + tid; k < n; k += CH_THREADS) {
                 const mimeo_hsp &hk = hs[b0 + k];
-                if (te <= hk.tstart && qe <= hk.qstart && bj > cand[b0 + k]) { cand[b0 + k] = bj; pred[b0 + k] = (int)j; }
+                const uint32_t ts = hk.tstart, qs = hk.qstart;
+                long long c = cand[b0 + k];
+                int pk = -2;
+                for (uint32_t ii = 0; ii < cnt; ii++)
+                    if (s_te[ii] <= ts && s_qe[ii] <= qs && s_b[ii] > c) { c = s_b[ii]; pk = (int)(t0 + ii); }
+                if (pk != -2) { cand[b0 + k] = c; pred[b0 + k] = pk; }
             }
             __syncthreads();
         }
