@@ -1,7 +1,8 @@
 // K5 — lastz `--chain` (reference call site src/mimeo/wrappers.py:1031 `--chain`).
 //
 // Work unit = one group = one (target scaffold, query scaffold, strand); one workgroup owns it:
-//   * rank-sort the group's HSPs by (tstart, qstart, length);
+//   * the HSPs of all groups are sorted by (group, tstart, qstart, length) with two stable
+//     device-wide radix sorts (microsatellite-rich units reach 10^5 HSPs: no O(n^2) sort);
 //   * chain DP  best[j] = score[j] + max(0, max{best[i] : i ends at or before the start of j in both
 //     sequences}), evaluated forward in tiles of 64: one wavefront finalises a tile (lane = HSP,
 //     64 shuffle steps), then the whole workgroup relaxes every later HSP against the tile's 64
@@ -10,6 +11,10 @@
 //     and the earliest chain end;
 //   * flag the chain and order the chained HSPs by (score desc, tstart, qstart, length) — the
 //     order in which K6 turns them into anchors.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "device_util.h"
 
 namespace mimeo {
@@ -28,7 +33,34 @@ __device__ __forceinline__ bool anchor_less(const mimeo_hsp &a, const mimeo_hsp 
     return hsp_less(a, b);
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ groups, const mimeo_hsp *__restrict__ in,
+// sort plumbing: key1 = (qstart, length), key2 = (start of the group's range, tstart)
+__global__ void k5_group_begin(const Group *__restrict__ groups, uint32_t *__restrict__ gb) {
+    const Group &G = groups[blockIdx.x];
+    for (uint64_t i = G.hsp_begin + threadIdx.x; i < G.hsp_end; i += blockDim.x) gb[i] = (uint32_t)G.hsp_begin;
+}
+__global__ void k5_key1(const mimeo_hsp *__restrict__ in, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = ((uint64_t)in[i].qstart << 32) | in[i].length;
+    val[i] = (uint32_t)i;
+}
+__global__ void k5_key2(const mimeo_hsp *__restrict__ in, const uint32_t *__restrict__ gb, const uint32_t *__restrict__ perm,
+                        uint64_t n, uint64_t *__restrict__ key) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = perm[i];
+    key[i] = ((uint64_t)gb[src] << 32) | in[src].tstart;
+}
+__global__ void k5_gather(const mimeo_hsp *__restrict__ in, const uint32_t *__restrict__ perm, uint64_t n,
+                          mimeo_hsp *__restrict__ hs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    mimeo_hsp h = in[perm[i]];
+    h.flags = 0;
+    hs[i] = h;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ groups,
                                                        mimeo_hsp *__restrict__ hs, long long *__restrict__ best,
                                                        long long *__restrict__ cand, int *__restrict__ pred,
                                                        uint32_t *__restrict__ order, int do_chain) {
@@ -42,18 +74,7 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
     __shared__ uint32_t s_te[CH_TILE], s_qe[CH_TILE];
     __shared__ long long s_b[CH_TILE];
     if (n == 0) { if (tid == 0) G.nchain = 0; return; }
-    // 1. rank sort into hs[b0 .. b0+n)
-    for (uint32_t i = tid; i < n; i += CH_THREADS) {
-        mimeo_hsp me = in[b0 + i];
-        uint32_t rank = 0;
-        for (uint32_t k = 0; k < n; k++) {
-            mimeo_hsp o = in[b0 + k];
-            if (hsp_less(o, me) || (!hsp_less(me, o) && k < i)) rank++;
-        }
-        me.flags = 0;
-        hs[b0 + rank] = me;
-    }
-    __syncthreads();
+    // 1. hs[b0 .. b0+n) arrives sorted by (tstart, qstart, length) (device-wide radix sorts, chain_device)
     if (do_chain) {
         for (uint32_t k = tid; k < n; k += CH_THREADS) { cand[b0 + k] = 0; pred[b0 + k] = -1; }
         __syncthreads();
@@ -139,7 +160,27 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
 int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps, int do_chain,
                  mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order) {
     if (!ngroups || !nhsps) return 0;
-    hipLaunchKernelGGL(k5_chain, dim3(ngroups), dim3(CH_THREADS), 0, stream(), d_groups, d_hsps, d_sorted, d_best,
+    if (nhsps >= (1ull << 32)) { set_error("more than 2^32 HSPs in one batch"); return MIMEO_ERR_LIMIT; }
+    hipStream_t st = stream();
+    static DeviceBuf kA, kB, vA, vB, gb, tmp;  // K5 runs on the calling thread only
+    int rc;
+    if ((rc = kA.reserve(nhsps * 8)) || (rc = kB.reserve(nhsps * 8)) || (rc = vA.reserve(nhsps * 4)) ||
+        (rc = vB.reserve(nhsps * 4)) || (rc = gb.reserve(nhsps * 4)))
+        return rc;
+    const dim3 blk(256), grd((uint32_t)((nhsps + 255) / 256));
+    hipLaunchKernelGGL(k5_group_begin, dim3(ngroups), blk, 0, st, (const Group *)d_groups, (uint32_t *)gb.p);
+    hipLaunchKernelGGL(k5_key1, grd, blk, 0, st, d_hsps, nhsps, (uint64_t *)kA.p, (uint32_t *)vA.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vA.p, (uint32_t *)vB.p,
+                                      (size_t)nhsps, 0, 64, st));
+    if ((rc = tmp.reserve(tb + 16))) return rc;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vA.p, (uint32_t *)vB.p,
+                                      (size_t)nhsps, 0, 64, st));
+    hipLaunchKernelGGL(k5_key2, grd, blk, 0, st, d_hsps, (const uint32_t *)gb.p, (const uint32_t *)vB.p, nhsps, (uint64_t *)kA.p);
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vB.p, (uint32_t *)vA.p,
+                                      (size_t)nhsps, 0, 64, st));
+    hipLaunchKernelGGL(k5_gather, grd, blk, 0, st, d_hsps, (const uint32_t *)vA.p, nhsps, d_sorted);
+    hipLaunchKernelGGL(k5_chain, dim3(ngroups), dim3(CH_THREADS), 0, st, d_groups, d_sorted, d_best,
                        d_cand, d_pred, d_order, do_chain);
     HIP_TRY(hipGetLastError());
     return 0;
