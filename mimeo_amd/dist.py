@@ -16,9 +16,13 @@ class Dist:
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.backend = None
         self._torch = None
+        # MIMEO_DIST_FORCE=1 creates the process group even for a single rank, so that the RCCL code
+        # path (device tensors, all_gather, all_reduce, barrier) can be exercised on a one-GPU box
+        self.active = False
+        self._force = os.environ.get('MIMEO_DIST_FORCE') == '1'
 
     def init(self, backend=None):
-        if self.world <= 1:
+        if self.world <= 1 and not self._force:
             return self
         import torch
         import torch.distributed as td
@@ -30,6 +34,12 @@ class Dist:
             if backend == 'nccl':
                 torch.cuda.set_device(self.local_rank)
             td.init_process_group(backend=backend)
+        self.active = True
+        # first collective now: communicator setup (seconds with RCCL) stays out of any timed region
+        warm = torch.zeros(1, dtype=torch.int64, device=self.device)
+        td.all_reduce(warm)
+        if backend == 'nccl':
+            torch.cuda.synchronize()
         return self
 
     @property
@@ -39,13 +49,13 @@ class Dist:
         return 'cpu'
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             import torch.distributed as td
             td.barrier()
 
     def max_float(self, x):
         """max over ranks of a python float (bench timing)."""
-        if self.world <= 1:
+        if not self.active:
             return x
         import torch.distributed as td
         t = self._torch.tensor([x], dtype=self._torch.float64, device=self.device)
@@ -53,7 +63,7 @@ class Dist:
         return float(t.item())
 
     def sum_int(self, x):
-        if self.world <= 1:
+        if not self.active:
             return int(x)
         import torch.distributed as td
         t = self._torch.tensor([int(x)], dtype=self._torch.int64, device=self.device)
@@ -62,7 +72,7 @@ class Dist:
 
     def allgather_records(self, arr):
         """Concatenate a structured numpy array over ranks, in rank order, on every rank."""
-        if self.world <= 1:
+        if not self.active:
             return arr
         import torch.distributed as td
         torch = self._torch

@@ -146,6 +146,25 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     assert b['config']['pair_strands_rank0'] < a['config']['pair_strands_rank0']
 
 
+def test_bench_under_rccl_single_rank(tmp_path):
+    """The collectives of the N>1 path through the real RCCL backend: one rank under torchrun with
+    MIMEO_DIST_FORCE=1 (two ranks cannot share a GPU under RCCL).  Device tensors, all_gather of
+    sizes and payload, all_reduce(MAX) of the time and the barrier all run as they do on 8 GPUs."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MIMEO_DIST_BACKEND='nccl', MIMEO_DIST_FORCE='1')
+    run = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', '1', '--workload', 'small', '--steps', '1',
+                          '--warmup', '1', '--no-cpu-baseline'], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    b = json.loads([l for l in run.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert b['n_gpus'] == 1 and b['result']['alignments'] > 0 and b['result']['regions'] > 0
+
+
 def test_lastz_shim_runs_the_reference_invocation(eng, tmp_path):
     """The literal argv the reference builds for lastz (wrappers.py:1025-1037) -> 13-field general
     rows that the reference's own awk filter turns into the same TAB block as the oracle."""
