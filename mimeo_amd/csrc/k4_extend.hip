@@ -197,14 +197,14 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(StrandView T, S
     }
 }
 
-// The same 32 steps as walk_window, as straight-line predicated code: eight table groups, no
-// per-lane branches.  A lane whose next group holds an N, an earlier seed hit or the sequence end
-// stops here and finishes the window in walk_window (rare; taken under a wave-uniform branch).
+// The same 32 steps as walk_window, as straight-line code without per-lane branches: the eight table
+// groups are applied to running values unconditionally, and the state in front of the first group that
+// cannot be applied — x-drop inside it, an N / earlier seed hit / the sequence end in it, or a walk that
+// was already finished — is kept aside (one select per value and group).  A lane stopped by a blocked
+// group finishes the window in walk_window (rare; taken under a wave-uniform branch).
 __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl,
                                                  uint32_t mdh, uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit,
                                                  int xdrop) {
-    bool act = !w.done, slow = false;
-    uint32_t slow_pos = 0;
     const uint32_t blocked = mnn | mH;
     // the eight table entries depend only on the masks: fetch them back to back, then run the
     // dependent score arithmetic on registers
@@ -214,26 +214,39 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
         const int pos = 4 * c;
         ent[c] = tab[((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8)];
     }
+    uint32_t nz = blocked | (blocked >> 1);
+    nz |= nz >> 2;                                // bit 4c: group c holds a blocked step
+    const uint32_t ng = (limit - w.k) >> 2;       // whole groups that still fit below the limit
+    int32_t R = w.run, B = w.best, sR = R, sB = B;
+    uint32_t BK = 0, sBK = 0, sC = 0;             // BK: steps at the best prefix relative to w.k (0 = unchanged)
+    bool stopped = w.done, slow = false, brkdone = false;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const int pos = 4 * c;
-        const bool can = act && (limit - w.k >= 4u) && !((blocked >> pos) & 0xFu);
-        if (act && !can) { slow = true; slow_pos = pos; }
-        act = act && can;
         const uint32_t e = ent[c];
         const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
-        const bool brk = act && (w.run + mn < w.best - xdrop);
-        const bool go = act && !brk;
-        const bool upd = go && (w.run + M > w.best);
-        w.bk = upd ? w.k + (e >> 30) + 1 : w.bk;
-        w.best = upd ? w.run + M : w.best;
-        w.run = go ? w.run + S : w.run;
-        w.k = go ? w.k + 4 : w.k;
-        w.done = w.done || brk;
-        act = go;
+        const bool blk = ((uint32_t)c >= ng) || ((nz >> (4 * c)) & 1u);
+        const bool brk = R + mn + xdrop < B;
+        const bool first = (blk || brk) && !stopped;
+        sR = first ? R : sR;
+        sB = first ? B : sB;
+        sBK = first ? BK : sBK;
+        sC = first ? (uint32_t)c : sC;
+        slow = slow || (first && blk);            // a blocked group wins over the x-drop test, as in walk_window
+        brkdone = brkdone || (first && !blk);
+        stopped = stopped || blk || brk;
+        const int32_t cand = R + M;
+        BK = cand > B ? (e >> 30) + (uint32_t)(4 * c + 1) : BK;
+        B = max(B, cand);
+        R += S;
     }
+    if (!stopped) { sR = R; sB = B; sBK = BK; sC = 8; }
+    w.run = sR;
+    w.best = sB;
+    w.bk = sBK ? w.k + sBK : w.bk;
+    w.k += 4u * sC;
+    w.done = w.done || brkdone;
     if (__ballot(slow)) {
-        if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, slow_pos);
+        if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, 4u * sC);
     }
 }
 
