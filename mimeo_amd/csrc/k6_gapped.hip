@@ -505,32 +505,38 @@ __device__ void wave_anchor_chunk(const StrandView &T, const StrandView &Q, cons
         atomicMax(packed, ((unsigned long long)(uint32_t)(bs + 8192) << 32) | (unsigned long long)(0xFFFFFFFFu - bw));
 }
 
-// anchors[b0 + r] = anchor point of the r-th chained HSP of the group (16 waves per group share
-// the (HSP, chunk) items round-robin)
+// packed[b0 + r] = best window of the r-th chained HSP of the group.  ANCHOR_SPLIT workgroups of 16
+// wavefronts share the (HSP, chunk) items of a group round-robin (the 5 Mbp self HSP alone has 1220
+// chunks); k6_anchor_final turns the packed maxima into anchor points.
+constexpr uint32_t ANCHOR_SPLIT = 16;
 __global__ __launch_bounds__(ANCHOR_THREADS) void k6_anchor_points(const Group *__restrict__ groups,
                                                                    const mimeo_hsp *__restrict__ hs,
                                                                    const uint32_t *__restrict__ order,
-                                                                   unsigned long long *__restrict__ packed,
-                                                                   uint2 *__restrict__ anchors) {
+                                                                   unsigned long long *__restrict__ packed) {
     const Group &G = groups[blockIdx.x];
     const uint64_t b0 = G.hsp_begin;
-    const uint32_t wave = threadIdx.x >> 6, nwaves = ANCHOR_THREADS / 64;
+    const uint32_t nw = ANCHOR_SPLIT * (ANCHOR_THREADS / 64), me = blockIdx.y * (ANCHOR_THREADS / 64) + (threadIdx.x >> 6);
     uint32_t item = 0;
     for (uint32_t r = 0; r < G.nchain; r++) {
         const mimeo_hsp h = hs[b0 + order[b0 + r]];
         if (h.length <= ANCHOR_W) continue;
         const uint32_t nch = (h.length - ANCHOR_W + 1 + ANCHOR_CHUNK - 1) / ANCHOR_CHUNK;
-        for (uint32_t c = 0; c < nch; c++, item++)
-            if (item % nwaves == wave) wave_anchor_chunk(G.T, G.Q, h, c, &packed[b0 + r]);
+        // my chunks of this HSP: c = first, first + nw, ...
+        const uint32_t first = (me + nw - item % nw) % nw;
+        for (uint32_t c = first; c < nch; c += nw) wave_anchor_chunk(G.T, G.Q, h, c, &packed[b0 + r]);
+        item += nch;
     }
-    __syncthreads();
-    for (uint32_t r = threadIdx.x; r < G.nchain; r += ANCHOR_THREADS) {
+}
+__global__ __launch_bounds__(256) void k6_anchor_final(const Group *__restrict__ groups, const mimeo_hsp *__restrict__ hs,
+                                                       const uint32_t *__restrict__ order,
+                                                       const unsigned long long *__restrict__ packed,
+                                                       uint2 *__restrict__ anchors) {
+    const Group &G = groups[blockIdx.x];
+    const uint64_t b0 = G.hsp_begin;
+    for (uint32_t r = threadIdx.x; r < G.nchain; r += blockDim.x) {
         const mimeo_hsp h = hs[b0 + order[b0 + r]];
         uint32_t off = h.length / 2;
-        if (h.length > ANCHOR_W) {
-            unsigned long long v = __hip_atomic_load(&packed[b0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            off = (0xFFFFFFFFu - (uint32_t)v) + ANCHOR_W / 2;
-        }
+        if (h.length > ANCHOR_W) off = (0xFFFFFFFFu - (uint32_t)packed[b0 + r]) + ANCHOR_W / 2;
         anchors[b0 + r] = make_uint2(h.tstart + off, h.qstart + off);
     }
 }
@@ -748,8 +754,10 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         if ((rc = g_astate.reserve((size_t)nhsps * 2))) return rc;  // state | defer count
         HIP_TRY(hipMemsetAsync(g_astate.p, 0, (size_t)nhsps * 2, st));
         if ((rc = g_cnt.reserve(16))) return rc;
-        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups, d_sorted,
-                           d_order, (unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);
+        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups, ANCHOR_SPLIT), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups,
+                           d_sorted, d_order, (unsigned long long *)g_packed.p);
+        hipLaunchKernelGGL(k6_anchor_final, dim3(ngroups), dim3(256), 0, st, (const Group *)d_groups, d_sorted, d_order,
+                           (const unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);
         for (;;) {
             HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 8, st));
             unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1;

@@ -12,8 +12,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
+#include <set>
 #include <thread>
 #include <tuple>
 
@@ -24,29 +26,94 @@ namespace mimeo {
 extern mimeo_stats g_stats;
 
 struct IndexCache {
-    // key: (scaffold address, strand, target-role sv plane in use).  Shared by the lanes: a build holds
-    // the lock (build_index uses one workspace and synchronises its stream before returning, so an index
-    // found in the map is complete whichever lane built it).
-    std::map<std::tuple<const Scaffold *, int, int>, SeedIndex> m;
+    // key: (scaffold address, strand, target-role sv plane in use).  A builder thread with a stream of its
+    // own works through the indexes in the order the units will need them, ahead of the lanes.  It issues
+    // one build each time a lane has launched a fast K4 kernel (a token): the radix sorts are bandwidth
+    // work that fits beside that VALU-bound kernel (0.6 ms vs 0.9 ms), and they are over before the next
+    // seed scan reads its offset arrays, so they neither share the chip with it nor evict what its count
+    // pass left in the Infinity Cache.  A lane that needs an index not yet built waits (and that lets the
+    // builder run at once).  build_index synchronises its stream before returning: a published index is
+    // complete.
+    typedef std::tuple<const Scaffold *, int, int> Key;
+    std::map<Key, SeedIndex> m;
     std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<Key, StrandView>> plan;
+    std::thread builder;
+    hipStream_t bstream = nullptr;
+    bool stop = false;
+    int rc = 0, tokens = 0, waiters = 0;
+    std::string err;
     float ms = 0;
+
+    static Key key_of(const Scaffold &s, int minus, bool as_target, StrandView *sv) {
+        const bool tsv = as_target && !minus && s.fwd.sv_target != nullptr;
+        *sv = (minus ? s.rc : s.fwd).view(tsv);
+        return std::make_tuple(&s, minus, tsv ? 1 : 0);
+    }
+    void want(const Scaffold &s, int minus, bool as_target, std::set<Key> &seen) {
+        StrandView sv;
+        Key k = key_of(s, minus, as_target, &sv);
+        if (seen.insert(k).second) plan.emplace_back(k, sv);
+    }
+    void start(hipStream_t st) {
+        bstream = st;
+        builder = std::thread([this] {
+            (void)hipSetDevice(device_id());
+            set_thread_stream(bstream);
+            for (auto &job : plan) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || tokens > 0 || waiters > 0; });
+                    if (stop) break;
+                    if (tokens > 0) tokens--;
+                }
+                SeedIndex idx;
+                float t = 0;
+                int r = build_index(job.second, idx, &t);
+                std::lock_guard<std::mutex> lk(mu);
+                ms += t;
+                if (r) { rc = r; err = last_error_copy(); cv.notify_all(); break; }
+                m.emplace(job.first, idx);
+                cv.notify_all();
+            }
+            set_thread_stream(nullptr);
+        });
+    }
     int get(const Scaffold &s, int minus, bool as_target, IndexView *out, StrandView *sv) {
-        bool tsv = as_target && !minus && s.fwd.sv_target != nullptr;
-        const Strand &st = minus ? s.rc : s.fwd;
-        *sv = st.view(tsv);
-        auto key = std::make_tuple(&s, minus, tsv ? 1 : 0);
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = m.find(key);
+        Key k = key_of(s, minus, as_target, sv);
+        std::unique_lock<std::mutex> lk(mu);
+        if (!m.count(k) && !rc && !stop) {
+            waiters++;
+            cv.notify_all();
+            cv.wait(lk, [&] { return m.count(k) || rc || stop; });
+            waiters--;
+        }
+        auto it = m.find(k);
         if (it == m.end()) {
-            SeedIndex idx;
-            int rc = build_index(*sv, idx, &ms);
-            if (rc) return rc;
-            it = m.emplace(key, idx).first;
+            set_error(rc ? err : std::string("seed index was not planned"));
+            return rc ? rc : MIMEO_ERR_ARG;
         }
         *out = it->second.view();
         return 0;
     }
+    void token() {  // a fast K4 kernel has just been launched
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (tokens < 2) tokens++;
+        }
+        cv.notify_all();
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        if (builder.joinable()) builder.join();
+    }
     void clear() {
+        finish();
         for (auto &kv : m) kv.second.release();
         m.clear();
     }
@@ -185,7 +252,7 @@ static void lane_main(Lane *ln, Shared *sh) {
         uint64_t nhits = 0, nh = 0;
         bool held = true;
         sh->gate.acquire(st);
-        std::function<void()> after_fast = [&] { if (held) { sh->gate.release(st, ln->heavy_end); held = false; } };
+        std::function<void()> after_fast = [&] { if (held) { sh->gate.release(st, ln->heavy_end); held = false; sh->cache->token(); } };
         rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm, sh->excl);
         if (!rc) rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, nhits, p, ln->unit_hsps, &nh, &ln->ms_ext, &after_fast);
         after_fast();  // no hits, or an error before the fast kernel
@@ -243,6 +310,8 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         g_lane[l].tm = JoinTiming();
         g_lane[l].ms_ext = 0;
     }
+    static hipStream_t index_stream = nullptr;
+    if (!index_stream) HIP_TRY(hipStreamCreateWithFlags(&index_stream, hipStreamNonBlocking));
     static Exclusive excl;  // events are created once; the lane set may change between calls
     {
         static bool ev_ok = false;
@@ -253,10 +322,11 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             }
             ev_ok = true;
         }
-        excl.n = nlanes;
+        excl.n = nlanes + 1;  // the index builder's stream also yields to the seed-scan fill
         for (int l = 0; l < nlanes; l++) excl.st[l] = g_lane[l].st;
+        excl.st[nlanes] = index_stream;
     }
-    const bool use_excl = nlanes > 1 && !(getenv("MIMEO_NO_EXCL") && atoi(getenv("MIMEO_NO_EXCL")));
+    const bool use_excl = !(getenv("MIMEO_NO_EXCL") && atoi(getenv("MIMEO_NO_EXCL")));
     // units in target-major order (stable in the caller's pair order): neighbouring units share the
     // target index, and the two lanes work on neighbouring units
     std::vector<uint64_t> ord(npairs);
@@ -269,10 +339,18 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                 units.push_back(Unit{ord[k], pair_t[ord[k]], pair_q[ord[k]], minus});
     std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
     IndexCache cache;
+    {
+        std::set<IndexCache::Key> seen;
+        for (const Unit &u : units) {
+            cache.want(A->scaf[u.tid], 0, true, seen);
+            cache.want(QG->scaf[u.qid], (int)u.minus, false, seen);
+        }
+    }
     float ms_chain = 0, ms_gapped = 0;
     int rc = 0;
     const size_t MAX_GROUPS = 8192;  // units per K5/K6 batch
     HIP_TRY(hipStreamSynchronize(stream()));
+    cache.start(index_stream);
     for (size_t b0 = 0; b0 < units.size() && !rc; b0 += MAX_GROUPS) {
         size_t b1 = std::min(units.size(), b0 + MAX_GROUPS);
         Batch batch;
