@@ -121,6 +121,8 @@ struct JoinTiming { float ms_count = 0, ms_fill = 0; };
 struct JoinCtx {
     unsigned long long *tile_count = nullptr, *tile_base = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    JoinTiming *pending_tm = nullptr;  // a speculative launch whose event times have not been read yet
+    const unsigned long long *total_dev() const { return tile_base + NTILE; }  // hit count of the last join
     void release();
 };
 // Lets one kernel run alone on the device while several lanes (streams) are active: begin() makes
@@ -147,8 +149,12 @@ struct Exclusive {
         mu.unlock();
     }
 };
+// spec_cap = 0: exact (one host round trip for the hit count).  spec_cap > 0: speculative — the buffer holds
+// spec_cap hits, nothing is read back, *nhits is 0 and the count stays on the device (ctx.total_dev()).
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex = nullptr);
+              JoinTiming *tm, Exclusive *ex = nullptr, uint64_t spec_cap = 0);
+void join_timing_flush(JoinCtx &ctx);
+constexpr int MIMEO_RETRY_EXACT = 1;  // internal: a speculative unit did not fit its buffers
 
 // K4: seed hits -> HSPs (k4_extend.hip); out_hsps holds mimeo_hsp records on the device
 struct ExtCounters;
@@ -159,9 +165,12 @@ struct ExtWork {  // per-lane work state of K4
 };
 // `after_fast` (optional) is called once, right after the fast kernel of the first attempt has been
 // launched: the point where a concurrent lane may start its own heavy phase.
+// d_nhits != null: speculative — `nhits` is the capacity of `hits`, the real count is read by the kernels
+// from *d_nhits and returned in *nhits_out; MIMEO_RETRY_EXACT if it exceeded the capacity.
 int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
-                         const std::function<void()> *after_fast = nullptr);
+                         const std::function<void()> *after_fast = nullptr, const unsigned long long *d_nhits = nullptr,
+                         uint64_t *nhits_out = nullptr);
 
 // K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
 constexpr int MAX_BATCH = 32;

@@ -111,12 +111,13 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
                                                              const uint32_t *__restrict__ offQ,
                                                              const uint32_t *__restrict__ posQ, int transitions,
                                                              const unsigned long long *__restrict__ tile_base,
-                                                             uint2 *__restrict__ hits) {
+                                                             uint2 *__restrict__ hits, unsigned long long cap) {
     __shared__ __attribute__((aligned(16))) uint32_t sT[TILE_WORDS + 4];
     __shared__ __attribute__((aligned(16))) uint32_t sQ[TILE_WORDS + 4];
     __shared__ uint32_t sPQ[FILL_QCACHE];
     __shared__ uint32_t wsum[2][FILL_THREADS / 64];
     const uint32_t tile = blockIdx.x;
+    if (tile_base[NTILE] > cap) return;  // speculative launch whose buffer is too small: the host redoes the unit
     unsigned long long out = tile_base[tile];
     if (tile_base[tile + 1] == out) return;  // empty tile
     load_tile_offsets_n(offT, tile, sT, FILL_THREADS);
@@ -198,49 +199,81 @@ void JoinCtx::release() {
 }
 
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex) {
+              JoinTiming *tm, Exclusive *ex, uint64_t spec_cap) {
     if (!ctx.tile_count) {
         HIP_TRY(hipMalloc((void **)&ctx.tile_count, (NTILE + 2) * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&ctx.tile_base, (NTILE + 2) * sizeof(unsigned long long)));
     }
     if (!ctx.ev[0])
         for (auto &e : ctx.ev) HIP_TRY(hipEventCreate(&e));
-    unsigned long long *g_tile_count = ctx.tile_count, *g_tile_base = ctx.tile_base;
-    hipEvent_t *g_ev = ctx.ev;
     hipStream_t st = stream();
-    HIP_TRY(hipEventRecord(g_ev[0], st));
-    hipLaunchKernelGGL(k3_join_count, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, Q.off, transitions, g_tile_count);
-    hipLaunchKernelGGL(k3_tile_scan, dim3(1), dim3(1024), 0, st, g_tile_count, g_tile_base);
-    HIP_TRY(hipEventRecord(g_ev[1], st));
-    unsigned long long total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, g_tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    *nhits = total;
-    if (total >= (1ull << 32)) {
-        set_error("one (target, query, strand) unit yields 2^32 or more seed hits (low-complexity sequence?): not supported");
-        return MIMEO_ERR_LIMIT;
+    // timing of the previous speculative launch on this context is collected now (its events have long fired)
+    if (ctx.pending_tm) {
+        float a = 0, b = 0;
+        if (hipEventSynchronize(ctx.ev[3]) == hipSuccess && hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]) == hipSuccess) {
+            ctx.pending_tm->ms_count += a;
+            ctx.pending_tm->ms_fill += b;
+        }
+        ctx.pending_tm = nullptr;
     }
-    int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
-    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx.ev[0], st));
+    hipLaunchKernelGGL(k3_join_count, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, Q.off, transitions, ctx.tile_count);
+    hipLaunchKernelGGL(k3_tile_scan, dim3(1), dim3(1024), 0, st, ctx.tile_count, ctx.tile_base);
+    HIP_TRY(hipEventRecord(ctx.ev[1], st));
+    unsigned long long total = 0, cap = ~0ull;
+    if (spec_cap) {
+        // no round trip: the fill (and K4 behind it) read the hit count from device memory; a count beyond
+        // the buffer makes them do nothing and the caller repeats the unit with the exact size
+        cap = spec_cap;
+        int rc = hits.reserve((size_t)spec_cap * sizeof(uint2));
+        if (rc) return rc;
+        *nhits = 0;
+    } else {
+        HIP_TRY(hipMemcpyAsync(&total, ctx.tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *nhits = total;
+        if (total >= (1ull << 32)) {
+            set_error("one (target, query, strand) unit yields 2^32 or more seed hits (low-complexity sequence?): not supported");
+            return MIMEO_ERR_LIMIT;
+        }
+        int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
+        if (rc) return rc;
+    }
     if (ex) ex->begin(st);
-    hipError_t e2 = hipEventRecord(g_ev[2], st);
-    if (total)
+    hipError_t e2 = hipEventRecord(ctx.ev[2], st);
+    if (spec_cap || total)
         hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(FILL_THREADS), 0, st, T.off, T.pos, Q.off, Q.pos, transitions,
-                           g_tile_base, (uint2 *)hits.p);
-    hipError_t e3 = hipEventRecord(g_ev[3], st);
+                           ctx.tile_base, (uint2 *)hits.p, cap);
+    hipError_t e3 = hipEventRecord(ctx.ev[3], st);
     if (ex) ex->end(st);
     HIP_TRY(e2);
     HIP_TRY(e3);
     HIP_TRY(hipGetLastError());
     if (tm) {
-        HIP_TRY(hipEventSynchronize(g_ev[3]));
-        float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, g_ev[0], g_ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, g_ev[2], g_ev[3]));
-        tm->ms_count += a;
-        tm->ms_fill += b;
+        if (spec_cap) {
+            ctx.pending_tm = tm;  // read at the next call on this context, or by join_timing_flush
+        } else {
+            HIP_TRY(hipEventSynchronize(ctx.ev[3]));
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]));
+            tm->ms_count += a;
+            tm->ms_fill += b;
+        }
     }
     return 0;
+}
+
+void join_timing_flush(JoinCtx &ctx) {
+    if (!ctx.pending_tm) return;
+    float a = 0, b = 0;
+    if (hipEventSynchronize(ctx.ev[3]) == hipSuccess && hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]) == hipSuccess &&
+        hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]) == hipSuccess) {
+        ctx.pending_tm->ms_count += a;
+        ctx.pending_tm->ms_fill += b;
+    }
+    ctx.pending_tm = nullptr;
 }
 
 }  // namespace mimeo

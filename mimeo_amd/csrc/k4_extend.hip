@@ -293,13 +293,18 @@ __device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, co
 
 template <int VARIANT>  // 1 = production; 2 = loads only, 3 = compute only (timing experiments, wrong results)
 __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
-                                                              const uint2 *__restrict__ hits, uint64_t nhits,
+                                                              const uint2 *__restrict__ hits, uint64_t nhits_arg,
                                                               int xdrop, int hspthresh, int transitions,
                                                               const uint32_t *__restrict__ group_tab,
                                                               ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                               uint64_t cand_cap, uint64_t *__restrict__ fkey,
                                                               uint32_t *__restrict__ fprev,
-                                                              uint2 *__restrict__ medq, int skip_diag0) {
+                                                              uint2 *__restrict__ medq, int skip_diag0,
+                                                              const unsigned long long *__restrict__ nhits_dev) {
+    // speculative launch: the count comes from the seed scan on the device, nhits_arg is the buffer capacity
+    // (a count beyond it means the scan wrote nothing: no work)
+    uint64_t nhits = nhits_arg;
+    if (nhits_dev) { const uint64_t t = *nhits_dev; nhits = t > nhits_arg ? 0 : t; }
     __shared__ uint32_t tab[GROUP_TAB];
     // per-wave staging of the three output queues: one global atomic per >= 64 records instead of
     // one per wavefront iteration (same-address atomics serialise at ~15 ns each)
@@ -908,7 +913,7 @@ void ExtWork::release() {
 
 int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
-                         const std::function<void()> *after_fast) {
+                         const std::function<void()> *after_fast, const unsigned long long *d_nhits, uint64_t *nhits_out) {
     hipStream_t st = stream();
     *nhsp = 0;
     if (T.len >= 0x7FFFFF00u || Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
@@ -925,7 +930,8 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
     });
     if (tab_rc || !g_group_tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
     HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
-    if (!nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
+    if (!nhits && !d_nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
+    unsigned long long total_h = nhits;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -954,7 +960,8 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
                            p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
-                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand)
+                           (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand, d_nhits)
+        if (variant == 0 && d_nhits) return MIMEO_RETRY_EXACT;  // the development variant has no capacity guard
         if (variant == 0)
             hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits,
                                (const unsigned long long *)nullptr, p->xdrop, p->hspthresh, p->transitions,
@@ -976,7 +983,10 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                            p->hspthresh, p->transitions, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                            (uint32_t *)W.fprev.p);
         HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
+        if (d_nhits) HIP_TRY(hipMemcpyAsync(&total_h, d_nhits, sizeof total_h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (nhits_out) *nhits_out = total_h;
+        if (d_nhits && total_h > nhits) return MIMEO_RETRY_EXACT;  // nothing was written; the caller repeats the unit
         if (c.nfollow) {
             uint64_t nf = c.nfollow;
             if ((rc = W.fkey2.reserve(nf * 8))) return rc;

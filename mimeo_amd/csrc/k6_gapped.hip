@@ -119,6 +119,18 @@ __device__ __forceinline__ void load_qbits(const StrandView &Q, uint32_t aq, int
 }
 
 // One-sided y-drop affine extension by one wavefront (all lanes return the same result).
+// Target bases of 32 consecutive DP rows i0 .. i0+31 (bit b <-> row i0 + b): one window load per 32 rows
+// instead of a dependent global load in every row; the caller fetches one block ahead.
+struct RowBases { uint32_t lo, hi, nm; };
+__device__ __forceinline__ RowBases load_row_bases(const StrandView &T, uint32_t at, int dir, uint32_t i0) {
+    if (dir > 0) {
+        const Win32 w = win32(T, (int32_t)(at + i0 - 1u));
+        return RowBases{w.lo, w.hi, w.nm};
+    }
+    const Win32 w = win32(T, (int32_t)at - (int32_t)i0 - 31);
+    return RowBases{__brev(w.lo), __brev(w.hi), __brev(w.nm)};
+}
+
 template <int WSTRIP>
 __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq, int dir,
                                        int32_t O, int32_t E, int32_t Y) {
@@ -172,11 +184,12 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         if (alive && j >= WINDOW - WSTRIP) over = true;
     }
     if (__ballot(over)) { best.overflow = 1; return best; }
+    RowBases rbase{0, 0, 0}, rnext = load_row_bases(T, at, dir, 1u);
     for (uint32_t i = 1; i <= lenA; i++) {
         const int32_t thr = best.score - Y;
-        const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
-        const Base1 ab = base_at(T, pa);
-        const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
+        const uint32_t rbit = (i - 1u) & 31u;
+        if (rbit == 0) { rbase = rnext; rnext = load_row_bases(T, at, dir, i + 32u); }
+        const uint32_t alo = (rbase.lo >> rbit) & 1u, ahi = (rbase.hi >> rbit) & 1u, an = (rbase.nm >> rbit) & 1u, acg = alo ^ ahi;
         // C of the column left of my strip (previous row): last slot of the previous lane
         const Cell p7 = dpp_cell<0x138, 0xf>(Cell{Cs[WSTRIP - 1], Cm[WSTRIP - 1], Cx[WSTRIP - 1]});
         // pass 1 (slots descending, in place): D(i,j) and H(i,j) = max(diagonal, D) overwrite the
@@ -347,11 +360,12 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
     if (lane == 63) sh.bnd[0][wave] = Cell{Cs[WS - 1], 0, 0};
     __syncthreads();
     uint32_t par = 0;
+    RowBases rbase{0, 0, 0}, rnext = load_row_bases(T, at, dir, 1u);
     for (uint32_t i = 1; i <= lenA; i++, par ^= 1u) {
         const int32_t thr = best.score - Y;
-        const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
-        const Base1 ab = base_at(T, pa);
-        const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
+        const uint32_t rbit = (i - 1u) & 31u;
+        if (rbit == 0) { rbase = rnext; rnext = load_row_bases(T, at, dir, i + 32u); }
+        const uint32_t alo = (rbase.lo >> rbit) & 1u, ahi = (rbase.hi >> rbit) & 1u, an = (rbase.nm >> rbit) & 1u, acg = alo ^ ahi;
         // C of the column left of my strip (previous row)
         Cell p7 = dpp_cell<0x138, 0xf>(Cell{Cs[WS - 1], Cm[WS - 1], Cx[WS - 1]});
         if (lane == 0) p7 = rw ? sh.bnd[par][(wave + 3u) & 3u] : Cell{NEG, 0, 0};

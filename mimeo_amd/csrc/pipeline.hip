@@ -141,18 +141,51 @@ struct Lane {
     DeviceBuf hits, unit_hsps;
     JoinTiming tm;
     float ms_ext = 0;
+    double excess = 1.0;  // largest hits / expected-on-random ratio of the units seen in this call
 };
 struct HeavyGate {
     std::mutex mu;
     hipEvent_t last = nullptr;
+    // hand-over bookkeeping (own lock: read while another lane holds `mu` for its whole heavy phase)
+    std::mutex hmu;
+    std::condition_variable hcv;
+    uint64_t seq = 0;                 // heavy phases issued so far
+    hipEvent_t last_fill = nullptr;   // "seed-scan fill finished" event of the latest one (may be null)
+    int active = 0;                   // lanes that may still issue a heavy phase
+    bool failed = false;
     void acquire(hipStream_t st) {
         mu.lock();
         if (last) (void)hipStreamWaitEvent(st, last, 0);
     }
-    void release(hipStream_t st, hipEvent_t mine) {
+    // returns the sequence number of the heavy phase just issued
+    uint64_t release(hipStream_t st, hipEvent_t mine, hipEvent_t fill_done) {
         (void)hipEventRecord(mine, st);
         last = mine;
+        uint64_t my;
+        {
+            std::lock_guard<std::mutex> lk(hmu);
+            my = ++seq;
+            last_fill = fill_done;
+        }
         mu.unlock();
+        hcv.notify_all();
+        return my;
+    }
+    // The small kernels that finish a unit should run beside the NEXT lane's fast K4 kernel, not in front of
+    // its seed scan (which would have to wait for them: it runs alone).  So a lane holds them back until the
+    // next heavy phase has been issued and orders them behind that phase's fill.
+    void tails_after_next_fill(hipStream_t st, uint64_t my) {
+        std::unique_lock<std::mutex> lk(hmu);
+        hcv.wait(lk, [&] { return seq > my || active <= 1 || failed; });
+        if (seq > my && last_fill) (void)hipStreamWaitEvent(st, last_fill, 0);
+    }
+    void lane_done(bool error) {
+        {
+            std::lock_guard<std::mutex> lk(hmu);
+            active--;
+            if (error) failed = true;
+        }
+        hcv.notify_all();
     }
 };
 constexpr int MAX_LANES = 4;
@@ -228,6 +261,7 @@ struct Shared {
     IndexCache *cache;
     HeavyGate gate;
     Exclusive *excl;
+    bool speculative = true, handover = true;
     Batch *batch;
 };
 
@@ -250,12 +284,35 @@ static void lane_main(Lane *ln, Shared *sh) {
         int rc;
         if ((rc = sh->cache->get(ts, 0, true, &ti, &tv)) || (rc = sh->cache->get(qs, (int)u.minus, false, &qi, &qv))) { fail(rc); break; }
         uint64_t nhits = 0, nh = 0;
-        bool held = true;
-        sh->gate.acquire(st);
-        std::function<void()> after_fast = [&] { if (held) { sh->gate.release(st, ln->heavy_end); held = false; sh->cache->token(); } };
-        rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm, sh->excl);
-        if (!rc) rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, nhits, p, ln->unit_hsps, &nh, &ln->ms_ext, &after_fast);
-        after_fast();  // no hits, or an error before the fast kernel
+        // Speculative first: buffers sized from the expected hit count (13 probes per query word on random
+        // sequence, scaled by the largest excess seen in this call), no host round trip between the seed
+        // scan and the fast K4 kernel, so the lane hands the heavy phase on at once.  A unit that does not
+        // fit (the kernels then do nothing) is repeated with the exact count.
+        const double expect = 13.0 * (double)ti.n * (double)qi.n / 16777216.0;
+        uint64_t spec_cap = sh->speculative ? (uint64_t)(expect * std::max(1.5, 1.25 * ln->excess)) + (4u << 20) : 0;
+        if (spec_cap >= (1ull << 32)) spec_cap = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            bool held = true;
+            sh->gate.acquire(st);
+            std::function<void()> after_fast = [&] {
+                if (!held) return;
+                held = false;
+                hipEvent_t fill_done = nullptr;
+                if (sh->excl) { const int me = sh->excl->index_of(st); if (me >= 0) fill_done = sh->excl->done[me]; }
+                const uint64_t my = sh->gate.release(st, ln->heavy_end, fill_done);
+                sh->cache->token();
+                if (sh->handover) sh->gate.tails_after_next_fill(st, my);
+            };
+            rc = join_hits(ln->jc, ti, qi, p->transitions, ln->hits, &nhits, &ln->tm, sh->excl, spec_cap);
+            if (!rc)
+                rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, spec_cap ? spec_cap : nhits, p, ln->unit_hsps, &nh,
+                                          &ln->ms_ext, &after_fast, spec_cap ? ln->jc.total_dev() : nullptr, &nhits);
+            after_fast();  // no hits, or an error before the fast kernel
+            if (rc != MIMEO_RETRY_EXACT) break;
+            spec_cap = 0;
+            rc = 0;
+        }
+        if (!rc && expect > 0) ln->excess = std::max(ln->excess, (double)nhits / expect);
         if (rc) { fail(rc); break; }
         {
             std::lock_guard<std::mutex> lk(sh->mu);
@@ -291,7 +348,9 @@ static void lane_main(Lane *ln, Shared *sh) {
         }
         // the copy reads unit_hsps, which the next unit of this lane overwrites: same stream, so ordered
     }
+    sh->gate.lane_done(sh->rc.load() != 0);
     (void)hipStreamSynchronize(st);
+    join_timing_flush(ln->jc);
     set_thread_stream(nullptr);
 }
 
@@ -309,6 +368,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         if (!g_lane[l].heavy_end) HIP_TRY(hipEventCreateWithFlags(&g_lane[l].heavy_end, hipEventDisableTiming));
         g_lane[l].tm = JoinTiming();
         g_lane[l].ms_ext = 0;
+        g_lane[l].excess = 1.0;
     }
     static hipStream_t index_stream = nullptr;
     if (!index_stream) HIP_TRY(hipStreamCreateWithFlags(&index_stream, hipStreamNonBlocking));
@@ -359,6 +419,9 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         Shared sh;
         sh.A = A; sh.QG = QG; sh.p = p; sh.units = &units; sh.begin = b0; sh.end = b1; sh.next = b0;
         sh.cache = &cache; sh.batch = &batch; sh.excl = use_excl ? &excl : nullptr;
+        sh.speculative = !(getenv("MIMEO_NO_SPEC") && atoi(getenv("MIMEO_NO_SPEC")));
+        sh.handover = !(getenv("MIMEO_NO_HANDOVER") && atoi(getenv("MIMEO_NO_HANDOVER")));
+        sh.gate.active = nlanes;
         std::vector<std::thread> th;
         for (int l = 1; l < nlanes; l++) th.emplace_back(lane_main, &g_lane[l], &sh);
         lane_main(&g_lane[0], &sh);  // the calling thread is lane 0
