@@ -144,7 +144,7 @@ def main():
     L = A.lengths
     LQ = B.lengths if B is not None else L
     ew, er = (int(args.emulate.split('/')[1]), int(args.emulate.split('/')[0])) if args.emulate else (dist.world, dist.rank)
-    mine = split_contiguous(band_order(pairs, nscaf, ew), lambda p: L[p[0]] * LQ[p[1]] * (3.0 if B is None and p[0] == p[1] else 1.0), ew, er)
+    mine = split_contiguous(band_order(pairs, nscaf, ew), lambda p: L[p[0]] * LQ[p[1]] * (1.3 if B is None and p[0] == p[1] else 1.0), ew, er)
     params = engine.default_params()
     names_sorted = sorted(names, key=lambda s: s.encode())
     cid = {n: i for i, n in enumerate(names_sorted)}
