@@ -291,11 +291,61 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
 // is redone by the single-wavefront kernels.
 constexpr int C4_WS = 4, C4_WCOLS = 64 * C4_WS, C4_THREADS = 256;
 
+// k6_dp4 carries (matches, mismatches) packed into one word, 16 bits each: a third less to select, scan and
+// exchange per cell.  Counts grow by one per row at most, so rows < 65535 cannot overflow them; longer half
+// extensions fall back to the single-wavefront kernels (unpacked).
+struct PCell {
+    int32_t s;
+    uint32_t c;  // matches | mismatches << 16
+};
+struct PBest {
+    int32_t s;
+    uint32_t j, c;
+};
+__device__ __forceinline__ PCell pcmax_left(const PCell &l, const PCell &r) { return r.s > l.s ? r : l; }
+template <int CTRL, int RMASK>
+__device__ __forceinline__ PCell dpp_pcell(const PCell &c) {
+    PCell o;
+    o.s = __builtin_amdgcn_update_dpp(NEG, c.s, CTRL, RMASK, 0xf, false);
+    o.c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.c, CTRL, RMASK, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ PCell wave_incl_maxscan_p(PCell v) {
+    v = pcmax_left(dpp_pcell<0x111, 0xf>(v), v);
+    v = pcmax_left(dpp_pcell<0x112, 0xf>(v), v);
+    v = pcmax_left(dpp_pcell<0x114, 0xf>(v), v);
+    v = pcmax_left(dpp_pcell<0x118, 0xf>(v), v);
+    v = pcmax_left(dpp_pcell<0x142, 0xa>(v), v);
+    v = pcmax_left(dpp_pcell<0x143, 0xc>(v), v);
+    return v;
+}
+template <int CTRL, int RMASK>
+__device__ __forceinline__ PBest dpp_pbest(const PBest &c) {
+    PBest o;
+    o.s = __builtin_amdgcn_update_dpp(NEG, c.s, CTRL, RMASK, 0xf, false);
+    o.j = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.j, CTRL, RMASK, 0xf, false);
+    o.c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.c, CTRL, RMASK, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ PBest pbmax_left(const PBest &l, const PBest &r) { return r.s > l.s ? r : l; }
+__device__ __forceinline__ PBest wave_best_p(PBest v) {
+    v = pbmax_left(dpp_pbest<0x111, 0xf>(v), v);
+    v = pbmax_left(dpp_pbest<0x112, 0xf>(v), v);
+    v = pbmax_left(dpp_pbest<0x114, 0xf>(v), v);
+    v = pbmax_left(dpp_pbest<0x118, 0xf>(v), v);
+    v = pbmax_left(dpp_pbest<0x142, 0xa>(v), v);
+    v = pbmax_left(dpp_pbest<0x143, 0xc>(v), v);
+    PBest t;
+    t.s = __builtin_amdgcn_readlane(v.s, 63); t.j = (uint32_t)__builtin_amdgcn_readlane((int)v.j, 63);
+    t.c = (uint32_t)__builtin_amdgcn_readlane((int)v.c, 63);
+    return t;
+}
+
 struct C4Shared {
-    Cell bnd[2][4];   // [row parity][wavefront]: C of the wavefront's last column
-    Cell tot[4];      // per-wavefront maximum of u
+    PCell bnd[2][4];  // [row parity][wavefront]: C of the wavefront's last column
+    PCell tot[4];     // per-wavefront maximum of u
     uint32_t first[4], last[4];
-    Best4 best[4];
+    PBest best[4];
     int flag;
 };
 
@@ -339,7 +389,7 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
     }
     // ---- row-by-row DP
     int32_t Cs[WS], Ds[WS];
-    uint32_t Cm[WS], Cx[WS], Dm[WS], Dx[WS];
+    uint32_t Cc[WS], Dc[WS];  // matches | mismatches << 16 (PCell)
     uint32_t wb = 0, wbase = 0;                      // window base column (multiple of 256), wavefront holding it
     uint32_t rw = wave, jb = rw * C4_WCOLS + lane * WS;  // my rank in the ring, my first column
     uint32_t qlo, qhi, qn;
@@ -349,82 +399,83 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
         uint32_t j = jb + s;
         int32_t v = j ? -O - (int32_t)j * E : 0;
         bool alive = j <= lenB && (j == 0 || v >= -Y);
-        Cs[s] = alive ? v : NEG; Cm[s] = 0; Cx[s] = 0;
-        Ds[s] = NEG; Dm[s] = 0; Dx[s] = 0;
+        Cs[s] = alive ? v : NEG; Cc[s] = 0;
+        Ds[s] = NEG; Dc[s] = 0;
     }
     {   // row 0 must fit the guaranteed part of the window
         uint32_t hi0 = 0;
         if (Y >= O + E) hi0 = min(lenB, (uint32_t)((Y - O) / E));
         if (hi0 >= 4 * C4_WCOLS - WS) { best.overflow = 1; return best; }
     }
-    if (lane == 63) sh.bnd[0][wave] = Cell{Cs[WS - 1], 0, 0};
+    if (lane == 63) sh.bnd[0][wave] = PCell{Cs[WS - 1], 0};
     __syncthreads();
     uint32_t par = 0;
     RowBases rbase{0, 0, 0}, rnext = load_row_bases(T, at, dir, 1u);
     for (uint32_t i = 1; i <= lenA; i++, par ^= 1u) {
+        // the packed counts hold 16 bits each: a longer extension is redone by the single-wavefront kernel
+        if (i >= 0xFFFFu) { best.overflow = 1; break; }
         const int32_t thr = best.score - Y;
         const uint32_t rbit = (i - 1u) & 31u;
         if (rbit == 0) { rbase = rnext; rnext = load_row_bases(T, at, dir, i + 32u); }
         const uint32_t alo = (rbase.lo >> rbit) & 1u, ahi = (rbase.hi >> rbit) & 1u, an = (rbase.nm >> rbit) & 1u, acg = alo ^ ahi;
         // C of the column left of my strip (previous row)
-        Cell p7 = dpp_cell<0x138, 0xf>(Cell{Cs[WS - 1], Cm[WS - 1], Cx[WS - 1]});
-        if (lane == 0) p7 = rw ? sh.bnd[par][(wave + 3u) & 3u] : Cell{NEG, 0, 0};
+        PCell p7 = dpp_pcell<0x138, 0xf>(PCell{Cs[WS - 1], Cc[WS - 1]});
+        if (lane == 0) p7 = rw ? sh.bnd[par][(wave + 3u) & 3u] : PCell{NEG, 0};
 #pragma unroll
         for (int s = WS - 1; s >= 0; s--) {
             const uint32_t j = jb + s;
             const bool exists = j <= lenB;
-            Cell dd{NEG, 0, 0}, g{NEG, 0, 0};
-            if (Ds[s] > NEGH) { dd.s = Ds[s] - E; dd.nm = Dm[s]; dd.nx = Dx[s]; }
-            if (Cs[s] > NEGH && Cs[s] - O - E > dd.s) { dd.s = Cs[s] - O - E; dd.nm = Cm[s]; dd.nx = Cx[s]; }
-            Cell pc = s ? Cell{Cs[s ? s - 1 : 0], Cm[s ? s - 1 : 0], Cx[s ? s - 1 : 0]} : p7;
+            PCell dd{NEG, 0}, g{NEG, 0};
+            if (Ds[s] > NEGH) { dd.s = Ds[s] - E; dd.c = Dc[s]; }
+            if (Cs[s] > NEGH && Cs[s] - O - E > dd.s) { dd.s = Cs[s] - O - E; dd.c = Cc[s]; }
+            PCell pc = s ? PCell{Cs[s ? s - 1 : 0], Cc[s ? s - 1 : 0]} : p7;
             if (pc.s > NEGH && j >= 1) {
                 uint32_t dl = alo ^ ((qlo >> s) & 1u), dh = ahi ^ ((qhi >> s) & 1u), nn = an | ((qn >> s) & 1u);
                 bool m = !(dl | dh | nn);
                 g.s = pc.s + sub_score(dl, dh, acg, nn);
-                g.nm = pc.nm + (m ? 1u : 0u);
-                g.nx = pc.nx + (m ? 0u : 1u);
+                g.c = pc.c + (m ? 1u : 0x10000u);
             }
             if (!exists) { dd.s = NEG; g.s = NEG; }
-            Ds[s] = dd.s; Dm[s] = dd.nm; Dx[s] = dd.nx;
-            Cell hh = g;
+            Ds[s] = dd.s; Dc[s] = dd.c;
+            PCell hh = g;
             if (dd.s > g.s) hh = dd;
-            Cs[s] = hh.s; Cm[s] = hh.nm; Cx[s] = hh.nx;
+            Cs[s] = hh.s; Cc[s] = hh.c;
         }
         // insertion state: u_k = H_k + (k - wb) * E; in-lane, in-wavefront (DPP), across wavefronts (LDS)
         const int32_t koff = (int32_t)(rw * C4_WCOLS + lane * WS);
-        Cell run{NEG, 0, 0};
+        PCell run{NEG, 0};
 #pragma unroll
         for (int s = 0; s < WS; s++) {
-            Cell u{Cs[s] > NEGH ? Cs[s] + (koff + s) * E : NEG, Cm[s], Cx[s]};
-            run = cmax_left(run, u);
+            PCell u{Cs[s] > NEGH ? Cs[s] + (koff + s) * E : NEG, Cc[s]};
+            run = pcmax_left(run, u);
         }
-        const Cell inc = wave_incl_maxscan(run);
+        const PCell inc = wave_incl_maxscan_p(run);
         if (lane == 63) sh.tot[wave] = inc;
         __syncthreads();
-        Cell acc{NEG, 0, 0};
-        for (uint32_t r = 0; r < rw; r++) acc = cmax_left(acc, sh.tot[(wbase + r) & 3u]);
-        acc = cmax_left(acc, dpp_cell<0x138, 0xf>(inc));
+        PCell acc{NEG, 0};
+        for (uint32_t r = 0; r < rw; r++) acc = pcmax_left(acc, sh.tot[(wbase + r) & 3u]);
+        acc = pcmax_left(acc, dpp_pcell<0x138, 0xf>(inc));
         uint32_t amask = 0;
-        Best4 rb{NEG, 0xFFFFFFFFu, 0, 0};
+        PBest rb{NEG, 0xFFFFFFFFu, 0};
 #pragma unroll
         for (int s = 0; s < WS; s++) {
-            Cell hh{Cs[s], Cm[s], Cx[s]};
-            Cell I{NEG, acc.nm, acc.nx};
+            PCell hh{Cs[s], Cc[s]};
+            PCell I{NEG, acc.c};
             if (acc.s > NEGH) I.s = acc.s - O - (koff + s) * E;
-            Cell u{hh.s > NEGH ? hh.s + (koff + s) * E : NEG, hh.nm, hh.nx};
-            acc = cmax_left(acc, u);
-            Cell c = hh;
+            PCell u{hh.s > NEGH ? hh.s + (koff + s) * E : NEG, hh.c};
+            acc = pcmax_left(acc, u);
+            PCell c = hh;
             if (I.s > c.s) c = I;
             const bool alive = (jb + s <= lenB) && c.s >= thr && c.s > NEGH;
-            Cs[s] = alive ? c.s : NEG; Cm[s] = c.nm; Cx[s] = c.nx;
+            Cs[s] = alive ? c.s : NEG; Cc[s] = c.c;
             if (!alive) Ds[s] = NEG;
             if (alive) {
                 amask |= 1u << s;
-                if (c.s > rb.s) { rb.s = c.s; rb.j = jb + s; rb.nm = c.nm; rb.nx = c.nx; }
+                if (c.s > rb.s) { rb.s = c.s; rb.j = jb + s; rb.c = c.c; }
             }
         }
         // publish: boundary cell for the next row, first / last live column, best cell
-        if (lane == 63) sh.bnd[par ^ 1u][wave] = Cell{Cs[WS - 1], Cm[WS - 1], Cx[WS - 1]};
+        if (lane == 63) sh.bnd[par ^ 1u][wave] = PCell{Cs[WS - 1], Cc[WS - 1]};
         const uint64_t ball = __ballot(amask != 0);
         uint32_t wfirst = 0xFFFFFFFFu, wlast = 0;
         if (ball) {
@@ -435,24 +486,24 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
             wfirst = cb + lf * WS + (uint32_t)__builtin_ctz(mf);
             wlast = cb + ll * WS + (31u - (uint32_t)__builtin_clz(ml));
         }
-        Best4 wbest{NEG, 0xFFFFFFFFu, 0, 0};
-        if (__ballot(rb.s > best.score)) wbest = wave_best(rb);
+        PBest wbest{NEG, 0xFFFFFFFFu, 0};
+        if (__ballot(rb.s > best.score)) wbest = wave_best_p(rb);
         if (lane == 0) { sh.first[wave] = wfirst; sh.last[wave] = wlast; sh.best[wave] = wbest; }
         __syncthreads();
         uint32_t first = 0xFFFFFFFFu, last = 0;
-        Best4 tb{NEG, 0xFFFFFFFFu, 0, 0};
+        PBest tb{NEG, 0xFFFFFFFFu, 0};
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             first = min(first, sh.first[w]);
             last = max(last, sh.last[w]);
-            const Best4 o = sh.best[w];
+            const PBest o = sh.best[w];
             if (o.s > tb.s || (o.s == tb.s && o.j < tb.j)) tb = o;
         }
         if (first == 0xFFFFFFFFu) break;
         if (last - wb >= 4 * C4_WCOLS - WS) { best.overflow = 1; break; }
         best.maxcols = max(best.maxcols, last - wb + 1);
         best.rows = i;
-        if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.nm; best.nx = tb.nx; }
+        if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.c & 0xFFFFu; best.nx = tb.c >> 16; }
         // slide the window by whole 256-column blocks: the ring of wavefronts rotates
         const uint32_t k = (first - wb) / C4_WCOLS;
         if (k) {
@@ -465,7 +516,7 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
 #pragma unroll
                 for (int s = 0; s < WS; s++) { Cs[s] = NEG; Ds[s] = NEG; }
                 load_qbits<WS>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
-                if (lane == 63) sh.bnd[par ^ 1u][wave] = Cell{NEG, 0, 0};
+                if (lane == 63) sh.bnd[par ^ 1u][wave] = PCell{NEG, 0};
             }
             __syncthreads();
         }

@@ -118,3 +118,27 @@ def test_wide_band_second_chance_and_limit(eng):
     with pytest.raises(RuntimeError, match='band'):
         eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=90000))
     g.close()
+
+
+def test_long_extension_beyond_packed_counts(eng):
+    """A 300 kb alignment with 3 % substitutions and a few indels: each half extension runs for more than
+    65535 rows, past what the packed match/mismatch counters of the four-wavefront DP kernel hold, so the
+    single-wavefront kernel must take over — same alignment, same identity counts as the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(123)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    core = rng.integers(0, 4, 300_000)
+    mut = core.copy()
+    sub = rng.random(core.size) < 0.03
+    mut[sub] = (mut[sub] + rng.integers(1, 4, int(sub.sum()))) & 3
+    for p in sorted(rng.integers(1000, core.size - 1000, 40).tolist(), reverse=True):  # indels of 1-3 bases
+        mut = np.delete(mut, slice(p, p + int(rng.integers(1, 4)))) if rng.random() < 0.5 else np.insert(mut, p, rng.integers(0, 4, int(rng.integers(1, 4))))
+    T = acgt[np.concatenate([rng.integers(0, 4, 5000), core, rng.integers(0, 4, 5000)])]
+    Q = acgt[np.concatenate([rng.integers(0, 4, 3000), mut, rng.integers(0, 4, 3000)])]
+    g = eng.Genome(['t', 'q'], [T, Q])
+    p = eng.default_params(strand=1)
+    got = eng.align_pair(g, 0, g, 1, p)
+    exp = O.align_pair(T.tobytes(), Q.tobytes(), O.default_params(strand=1))
+    assert exp.size >= 1 and int((exp['tend'] - exp['tstart']).max()) > 280_000
+    _cmp(got, exp, 'long', ordered=True)
+    g.close()
