@@ -262,6 +262,7 @@ struct Shared {
     HeavyGate gate;
     Exclusive *excl;
     bool speculative = true, handover = true;
+    uint64_t spec_shrink = 0;
     Batch *batch;
 };
 
@@ -290,6 +291,7 @@ static void lane_main(Lane *ln, Shared *sh) {
         // fit (the kernels then do nothing) is repeated with the exact count.
         const double expect = 13.0 * (double)ti.n * (double)qi.n / 16777216.0;
         uint64_t spec_cap = sh->speculative ? (uint64_t)(expect * std::max(1.5, 1.25 * ln->excess)) + (4u << 20) : 0;
+        if (spec_cap && sh->spec_shrink > 0) spec_cap = spec_cap / sh->spec_shrink + 1;  // tests: force the retry path
         if (spec_cap >= (1ull << 32)) spec_cap = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
             bool held = true;
@@ -421,6 +423,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         sh.cache = &cache; sh.batch = &batch; sh.excl = use_excl ? &excl : nullptr;
         sh.speculative = !(getenv("MIMEO_NO_SPEC") && atoi(getenv("MIMEO_NO_SPEC")));
         sh.handover = !(getenv("MIMEO_NO_HANDOVER") && atoi(getenv("MIMEO_NO_HANDOVER")));
+        sh.spec_shrink = getenv("MIMEO_SPEC_SHRINK") ? (uint64_t)atol(getenv("MIMEO_SPEC_SHRINK")) : 0;
         sh.gate.active = nlanes;
         std::vector<std::thread> th;
         for (int l = 1; l < nlanes; l++) th.emplace_back(lane_main, &g_lane[l], &sh);

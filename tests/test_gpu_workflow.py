@@ -192,3 +192,29 @@ def test_lastz_shim_runs_the_reference_invocation(eng, tmp_path):
     assert P.filter_project_sort(text, 100, 80) == P.filter_project_sort('\n'.join(exp), 100, 80)
     bad = subprocess.run([sys.executable, '-m', 'mimeo_amd.lastz_shim', ta, qa, '--seed=match12'], cwd=root, capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+def test_pipeline_modes_give_identical_alignments(tmp_path):
+    """The scheduling options of the unit pipeline must not change a single record: one lane vs two,
+    speculative buffers vs exact, and speculative buffers that are too small (every unit is then repeated
+    with the exact size: MIMEO_SPEC_SHRINK forces that path)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from mimeo_amd import engine\n"
+            "from mimeo_amd.synth import synth_genome\n"
+            "engine.init(0)\n"
+            "n, s = synth_genome(77, 1_500_000, 3, repeat_frac=0.08, families=6, cons_len=(300, 2500))\n"
+            "g = engine.Genome(n, s)\n"
+            "a = engine.align_pairs(g, None, [(t, q) for t in range(3) for q in range(3)])\n"
+            "print(a.size, hashlib.md5(a.tobytes()).hexdigest(), engine.stats()['seed_hits'])\n") % root
+    outs = {}
+    for tag, env in (('default', {}), ('one_lane', {'MIMEO_LANES': '1'}), ('exact', {'MIMEO_NO_SPEC': '1'}),
+                     ('no_handover', {'MIMEO_NO_HANDOVER': '1'}), ('retry', {'MIMEO_SPEC_SHRINK': '1000'}),
+                     ('three_lanes', {'MIMEO_LANES': '3'})):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        outs[tag] = r.stdout.strip().split('\n')[-1]
+    assert len(set(outs.values())) == 1, outs
+    assert int(outs['default'].split()[0]) > 10
