@@ -72,6 +72,7 @@ int mimeo_init(int device) {
 }
 
 void mimeo_shutdown(void) {
+    if (g_init) release_pipeline_buffers();
     if (g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
     g_init = false;
 }

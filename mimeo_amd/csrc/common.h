@@ -203,6 +203,8 @@ int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint3
 int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
 
+void release_pipeline_buffers();  // pipeline.hip
+
 // K8: tandem scorer (k8_tandem.hip); host in, host out
 int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch,
                          int minscore, int maxperiod, uint32_t *h_masked);

@@ -356,6 +356,23 @@ static void lane_main(Lane *ln, Shared *sh) {
     set_thread_stream(nullptr);
 }
 
+// mimeo_shutdown: give the lanes' work buffers and streams back
+void release_pipeline_buffers() {
+    for (Lane &l : g_lane) {
+        if (l.st) (void)hipStreamSynchronize(l.st);
+        l.jc.release();
+        l.ew.release();
+        l.hits.release();
+        l.unit_hsps.release();
+        if (l.heavy_end) { (void)hipEventDestroy(l.heavy_end); l.heavy_end = nullptr; }
+        if (l.st) { (void)hipStreamDestroy(l.st); l.st = nullptr; }
+    }
+    g_hsp_batch.release();
+    g_scratch.release();
+    g_aln.release();
+    g_groups.release();
+}
+
 int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
     auto t0 = std::chrono::steady_clock::now();
