@@ -27,6 +27,22 @@ __device__ __forceinline__ void load_tile_offsets(const uint32_t *__restrict__ o
     if (threadIdx.x == 0) s[TILE_WORDS] = off[(size_t)tile * TILE_WORDS + TILE_WORDS];
 }
 
+// same sum, plus the set of non-empty neighbours: bit 0 = w itself, bit j + 1 = w ^ (1 << j)
+__device__ __forceinline__ uint32_t neighbour_sum_mask(const uint32_t *sQ, uint32_t w, int transitions, uint32_t &mask) {
+    uint32_t sum = sQ[w + 1] - sQ[w];
+    mask = sum ? 1u : 0u;
+    if (transitions) {
+#pragma unroll
+        for (int j = 0; j < SEED_WEIGHT; j++) {
+            const uint32_t w2 = w ^ (1u << j);
+            const uint32_t c = sQ[w2 + 1] - sQ[w2];
+            sum += c;
+            mask |= c ? (2u << j) : 0u;
+        }
+    }
+    return sum;
+}
+
 __device__ __forceinline__ uint32_t neighbour_sum(const uint32_t *sQ, uint32_t w, int transitions) {
     uint32_t sum = sQ[w + 1] - sQ[w];
     if (transitions) {
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
     for (uint32_t e0 = 0; e0 < nT; e0 += FILL_THREADS, par ^= 1u) {
         const uint32_t e = e0 + threadIdx.x;
         const uint32_t g = t0 + e;
-        uint32_t w = 0, c = 0;
+        uint32_t w = 0, c = 0, nmask = 0;
         if (e < nT) {
             uint32_t lo = 0, hi = TILE_WORDS;  // largest w with sT[w] <= g
             while (hi - lo > 1) {
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
                 if (sT[mid] <= g) lo = mid; else hi = mid;
             }
             w = lo;
-            c = neighbour_sum(sQ, w, transitions);
+            c = neighbour_sum_mask(sQ, w, transitions, nmask);
         }
         uint32_t inc = c;
         for (int o = 1; o < 64; o <<= 1) {
@@ -164,8 +180,10 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
         if (c) {
             const uint32_t tp = posT[g];
             uint2 *dst = hits + out + (wbase + inc - c);
-            for (int j = -1; j < (transitions ? SEED_WEIGHT : 0); j++) {
-                const uint32_t w2 = j < 0 ? w : (w ^ (1u << j));
+            // only the non-empty neighbours (3-4 of the 13 on random sequence), in the same order as before
+            for (uint32_t m = nmask; m; m &= m - 1u) {
+                const uint32_t jj = (uint32_t)__builtin_ctz(m);
+                const uint32_t w2 = jj ? (w ^ (1u << (jj - 1u))) : w;
                 const uint32_t q0 = sQ[w2], q1 = sQ[w2 + 1];
                 if (qcached)
                     for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, sPQ[b - q0t]);
