@@ -215,8 +215,9 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
         ent[c] = tab[((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8)];
     }
     uint32_t nz = blocked | (blocked >> 1);
-    nz |= nz >> 2;                                // bit 4c: group c holds a blocked step
-    const uint32_t ng = (limit - w.k) >> 2;       // whole groups that still fit below the limit
+    nz |= nz >> 2;                                // bit 4c: group c holds a blocked step ...
+    const uint32_t ng = (limit - w.k) >> 2;       // ... or does not fit below the limit any more (one test per
+    nz |= ng >= 8u ? 0u : (0xFFFFFFFFu << (4u * ng));  // group instead of two: compares issue at half rate)
     int32_t R = w.run, B = w.best, sR = R, sB = B;
     uint32_t BK = 0, sBK = 0, sC = 0;             // BK: steps at the best prefix relative to w.k (0 = unchanged)
     bool stopped = w.done, slow = false, brkdone = false;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
     for (int c = 0; c < 8; c++) {
         const uint32_t e = ent[c];
         const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
-        const bool blk = ((uint32_t)c >= ng) || ((nz >> (4 * c)) & 1u);
+        const bool blk = (nz >> (4 * c)) & 1u;
         const bool brk = R + mn + xdrop < B;
         const bool first = (blk || brk) && !stopped;
         sR = first ? R : sR;
