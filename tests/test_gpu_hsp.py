@@ -54,6 +54,36 @@ def test_hsps_self_pair_trivial_diagonal(eng):
     g.close()
 
 
+def test_hsps_self_pair_with_n_runs_and_soft_mask(eng):
+    """The main diagonal of a self unit is replayed on the seed-validity planes (k4_diag0): N runs longer
+    than the x-drop allows cut it into several HSPs, shorter ones are bridged, and soft-masked stretches have
+    no target seeds — all of it must match the sequential oracle, and so must the full alignment."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(9)
+    names, seqs = synth_genome(43, 400_000, 1, repeat_frac=0.1, families=3, cons_len=(300, 2000))
+    S = seqs[0].copy()
+    for ln in (1, 3, 8, 9, 10, 12, 40, 200, 5000):  # 9 Ns cost 900 < xdrop, 10 cost 1000 > xdrop
+        p = int(rng.integers(1000, S.size - 6000))
+        S[p:p + ln] = ord('N')
+    for _ in range(20):
+        p = int(rng.integers(0, S.size - 3000))
+        S[p:p + int(rng.integers(20, 2500))] |= 0x20
+    S[:50] = ord('N')
+    S[-30:] |= 0x20
+    g = eng.Genome(['s'], [S])
+    for strand in (0, 1):
+        got = eng.ungapped_hsps(g, 0, g, 0, strand, eng.default_params(chain=0))
+        exp = O.ungapped_hsps(S.tobytes(), S.tobytes(), strand, O.default_params(chain=0))
+        _cmp(got, exp, ('self-masked', strand))
+    diag = got if False else eng.ungapped_hsps(g, 0, g, 0, 0, eng.default_params(chain=0))
+    on_diag = diag[diag['tstart'] == diag['qstart']]
+    assert on_diag.size >= 4  # the long N runs split the trivial diagonal
+    a, b = eng.align_pair(g, 0, g, 0), O.align_pair(S.tobytes(), S.tobytes())
+    cols = ['tstart', 'tend', 'qstart', 'qend', 'score', 'id_n', 'id_d', 'qstrand']
+    assert np.array_equal(np.sort(a[cols], order=cols), np.sort(b[cols], order=cols))
+    g.close()
+
+
 def test_hsps_with_n_runs_lowercase_and_no_entropy(eng):
     from oracle import oracle as O
     rng = np.random.default_rng(5)
