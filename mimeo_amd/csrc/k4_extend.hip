@@ -727,9 +727,10 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(StrandView T, St
                                                                 ExtCounters *__restrict__ ctr, Cand *__restrict__ cand,
                                                                 uint64_t cand_cap, uint64_t *__restrict__ bigseg) {
     __shared__ uint32_t tab[GROUP_TAB];
+    const uint64_t nseg = *nseg_dev;
+    if ((uint64_t)blockIdx.x * EXT_THREADS >= nseg) return;  // the grid is sized for the followers, segments are fewer
     for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
     __syncthreads();
-    const uint64_t nseg = *nseg_dev;
     const uint64_t sid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x;
     if (sid >= nseg) return;
     const uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
@@ -955,7 +956,10 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
         HIP_TRY(hipMemsetAsync(W.nsel.p, 0, 16, st));
         uint64_t nb = (nhits + FAST_THREADS - 1) / FAST_THREADS;
-        if (nb > 256 * 16) nb = 256 * 16;  // grid-stride: the LDS table is loaded once per workgroup
+        // grid-stride over one resident set of workgroups (4 per CU): each loads the 16 KiB group table once.  Four
+        // times as many workgroups cost 12 % of the kernel (0.87 -> 0.76 ms per C2 unit with 1024).
+        static const uint64_t nb_cap = getenv("MIMEO_K4_BLOCKS") ? (uint64_t)atol(getenv("MIMEO_K4_BLOCKS")) : 1024;
+        if (nb > nb_cap) nb = nb_cap;
         // target and query are the same strand of the same scaffold: diagonal 0 is handled by k4_diag0
         const int same_strand = (T.pw == Q.pw && T.len == Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1 : 0;
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
@@ -973,7 +977,7 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         else K4_LAUNCH(1);
         if (after_fast && attempt == 0) (*after_fast)();
         // walks still alive after the frame -> generic kernel; beyond LONG_WINDOWS -> wavefront kernel
-        hipLaunchKernelGGL(k4_extend_generic, dim3(2048), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.medq.p,
+        hipLaunchKernelGGL(k4_extend_generic, dim3(512), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.medq.p,
                            (uint64_t)0, (const unsigned long long *)&W.ctr->nmed, p->xdrop, p->hspthresh, p->transitions,
                            (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                            (uint32_t *)W.fprev.p, (uint2 *)W.longq.p, 0);
