@@ -55,7 +55,7 @@ enum { MIMEO_STRAND_PLUS = 1, MIMEO_STRAND_MINUS = 2, MIMEO_STRAND_BOTH = 3 };
  */
 typedef struct mimeo_params {
     int32_t hspthresh;    /* --hspthresh [3000]; also the gapped threshold (lastz default)  */
-    int32_t xdrop;        /* ungapped x-drop [910 = 10*sub[A][A]]                          */
+    int32_t xdrop;        /* ungapped x-drop [910 = 10*sub[A][A]]; >= 500 (MIMEO_ERR_ARG below)  */
     int32_t ydrop;        /* gapped y-drop [9400 = open + 300*extend]                      */
     int32_t gap_open;     /* [400]                                                        */
     int32_t gap_extend;   /* [30]                                                         */

@@ -153,11 +153,25 @@ int mimeo_genome_length(const mimeo_genome *g, uint32_t scaf, uint64_t *length) 
     return MIMEO_OK;
 }
 
-static int check_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, const void *p,
+// parameter domain of the kernels (include/mimeo_hip.h, mimeo_params)
+static int check_params(const mimeo_params *p) {
+    // the gap-free walk applies four columns at a time; that is exact only while four HOXD70 columns
+    // (at most 4 * 125) cannot exceed the x-drop
+    if (p->xdrop < 500) { set_error("xdrop below 500 is not supported (the extension walks four columns per step)"); return MIMEO_ERR_ARG; }
+    if (p->xdrop > 30000 || p->hspthresh < 0 || p->ydrop < 0 || p->gap_open < 0 || p->gap_extend <= 0) {
+        set_error("alignment parameter out of range");
+        return MIMEO_ERR_ARG;
+    }
+    if (!(p->strand & MIMEO_STRAND_BOTH)) { set_error("strand selects nothing"); return MIMEO_ERR_ARG; }
+    return 0;
+}
+
+static int check_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, const mimeo_params *p,
                       const void *out, const void *nout) {
     int rc = need_init();
     if (rc) return rc;
     if (!T || !Q || !p || !out || !nout) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    if ((rc = check_params(p))) return rc;
     if (tid >= T->scaf.size() || qid >= Q->scaf.size()) { set_error("scaffold id out of range"); return MIMEO_ERR_ARG; }
     return 0;
 }
@@ -258,6 +272,7 @@ int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32
     int rc = need_init();
     if (rc) return rc;
     if (!A || !p || !out || !nout || (npairs && (!pair_t || !pair_q))) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    if ((rc = check_params(p))) return rc;
     return align_pairs_impl(A, B, pair_t, pair_q, npairs, p, out, nout);
 }
 

@@ -123,3 +123,17 @@ def test_hsps_low_complexity(eng):
         exp = O.ungapped_hsps(T.tobytes(), Q.tobytes(), strand, O.default_params(chain=0))
         _cmp(got, exp, ('ssr', strand))
     g.close()
+
+
+def test_parameter_domain_is_enforced(eng):
+    """xdrop below 4 x 125 would break the four-columns-per-step walk: the ABI refuses it instead of computing
+    something else (found by scripts/soak.py); other nonsense is refused too."""
+    names, seqs = synth_genome(3, 40_000, 2)
+    g = eng.Genome(names, seqs)
+    for kw, msg in ((dict(xdrop=340), 'xdrop'), (dict(gap_extend=0), 'out of range'), (dict(strand=0), 'strand')):
+        with pytest.raises(RuntimeError, match=msg):
+            eng.ungapped_hsps(g, 0, g, 1, 0, eng.default_params(**kw))
+        with pytest.raises(RuntimeError, match=msg):
+            eng.align_pairs(g, None, [(0, 1)], eng.default_params(**kw))
+    assert eng.ungapped_hsps(g, 0, g, 1, 0, eng.default_params(xdrop=500)).size >= 0
+    g.close()
