@@ -689,12 +689,155 @@ __global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, co
 
 // second chance for half extensions whose band outgrew the 1024-column window: 2048 columns
 __global__ __launch_bounds__(64) void k6_dp_wide(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
-                                                 HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+                                                 HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y,
+                                                 unsigned int *__restrict__ novf, unsigned int *__restrict__ ovf_list) {
     const DpJob job = jobs[blockIdx.x];
     if (!res[job.slot].overflow) return;
     const Group &G = groups[job.group];
     HalfResult r = wave_half_extend<32>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
-    if (threadIdx.x == 0) res[job.slot] = r;
+    if (threadIdx.x == 0) {
+        res[job.slot] = r;
+        if (r.overflow) ovf_list[atomicAdd(novf, 1u)] = blockIdx.x;  // band beyond 2048 columns: k6_dp_any
+    }
+}
+
+// ---- last resort: a half extension whose band does not fit 2048 columns (tandem arrays: every shift by a
+// period scores almost as well, so the live band grows with the array).  One workgroup of 1024 threads, the DP
+// rows in global memory as a ring of ANY_COLS columns (two rows: previous / current), three passes per row
+// with the same rules and tie-breaks as wave_half_extend.  Slow (a few microseconds per row plus ~1 ns per
+// live cell) but exact; only jobs that overflowed the register kernels come here.
+constexpr uint32_t ANY_COLS = 1u << 16;   // live band + one row's growth must stay below this
+constexpr int ANY_THREADS = 1024;
+struct AnyRow {  // one DP row in global memory, indexed by column & (ANY_COLS - 1)
+    int32_t *cs, *ds;
+    uint32_t *cm, *cx, *dm, *dx;
+};
+__device__ __forceinline__ AnyRow any_row(uint32_t *base, uint32_t parity) {
+    uint32_t *b = base + (size_t)parity * 6u * ANY_COLS;
+    return AnyRow{(int32_t *)b, (int32_t *)(b + ANY_COLS), b + 2u * ANY_COLS, b + 3u * ANY_COLS, b + 4u * ANY_COLS, b + 5u * ANY_COLS};
+}
+constexpr size_t ANY_SLOT_WORDS = 2u * 6u * (size_t)ANY_COLS;  // per job
+
+__global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
+                                                         const unsigned int *__restrict__ list, uint32_t first,
+                                                         HalfResult *__restrict__ res, uint32_t *__restrict__ scratch,
+                                                         int32_t O, int32_t E, int32_t Y) {
+    __shared__ Cell s_scan[ANY_THREADS / 64];
+    __shared__ Best4 s_best[ANY_THREADS / 64];
+    __shared__ uint32_t s_first[ANY_THREADS / 64], s_last[ANY_THREADS / 64];
+    const DpJob job = jobs[list[first + blockIdx.x]];
+    const Group &G = groups[job.group];
+    const StrandView &T = G.T, &Q = G.Q;
+    const uint32_t at = job.at, aq = job.aq;
+    const int dir = job.dir;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
+    uint32_t *base = scratch + (size_t)blockIdx.x * ANY_SLOT_WORDS;
+    const uint32_t M = ANY_COLS - 1u;
+    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0};
+    // row 0: C(0,j) = -O - j*E while that is within the y-drop
+    uint32_t lo = 0, hi = 0;
+    if (Y >= O + E) hi = min(lenB, (uint32_t)((Y - O) / E));
+    const uint32_t ext = (uint32_t)((Y + 200) / E) + 2u;  // how far an insertion can carry a live cell to the right
+    bool overflow = hi + ext + 2u >= ANY_COLS;
+    {
+        AnyRow r0 = any_row(base, 0);
+        for (uint32_t j = tid; j <= hi && !overflow; j += ANY_THREADS) {
+            r0.cs[j & M] = j ? -O - (int32_t)j * E : 0; r0.cm[j & M] = 0; r0.cx[j & M] = 0;
+            r0.ds[j & M] = NEG; r0.dm[j & M] = 0; r0.dx[j & M] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t par = 0;
+    for (uint32_t i = 1; i <= lenA && !overflow; i++, par ^= 1u) {
+        const AnyRow P = any_row(base, par), N = any_row(base, par ^ 1u);
+        const int32_t thr = best.score - Y;
+        const int32_t pa = dir > 0 ? (int32_t)(at + i - 1) : (int32_t)(at - i);
+        const Base1 ab = base_at(T, pa);
+        const uint32_t alo = ab.lo, ahi = ab.hi, an = ab.nm, acg = alo ^ ahi;
+        const uint32_t hx = min(lenB, hi + 1u + ext);  // last column that can be alive in this row
+        const uint32_t ncols = hx - lo + 1u;
+        if (ncols + 2u >= ANY_COLS) { overflow = true; break; }
+        // every thread owns one contiguous chunk of the row's columns (the insertion scan runs left to right)
+        const uint32_t chunk = (ncols + ANY_THREADS - 1) / ANY_THREADS;
+        const uint32_t j0 = lo + tid * chunk, j1 = min(hx + 1u, j0 + chunk);  // [j0, j1), possibly empty
+        // pass 1: D and H = max(diagonal, D) from the previous row (dead outside [lo, hi])
+        Cell run{NEG, 0, 0};
+        for (uint32_t j = j0; j < j1; j++) {
+            const bool in = j <= hi;  // j >= lo holds
+            const int32_t cp = in ? P.cs[j & M] : NEG, dp = in ? P.ds[j & M] : NEG;
+            Cell dd{NEG, 0, 0}, g{NEG, 0, 0};
+            if (dp > NEGH) { dd.s = dp - E; dd.nm = P.dm[j & M]; dd.nx = P.dx[j & M]; }
+            if (cp > NEGH && cp - O - E > dd.s) { dd.s = cp - O - E; dd.nm = P.cm[j & M]; dd.nx = P.cx[j & M]; }
+            if (j >= 1 && j - 1 >= lo && j - 1 <= hi) {
+                const int32_t pc = P.cs[(j - 1) & M];
+                if (pc > NEGH) {
+                    const Base1 qb = base_at(Q, dir > 0 ? (int32_t)(aq + j - 1) : (int32_t)(aq - j));
+                    const uint32_t dl = alo ^ qb.lo, dh = ahi ^ qb.hi, nn = an | qb.nm;
+                    const bool m = !(dl | dh | nn);
+                    g.s = pc + sub_score(dl, dh, acg, nn);
+                    g.nm = P.cm[(j - 1) & M] + (m ? 1u : 0u);
+                    g.nx = P.cx[(j - 1) & M] + (m ? 0u : 1u);
+                }
+            }
+            N.ds[j & M] = dd.s; N.dm[j & M] = dd.nm; N.dx[j & M] = dd.nx;
+            Cell hh = g;  // diagonal preferred on ties
+            if (dd.s > g.s) hh = dd;
+            N.cs[j & M] = hh.s; N.cm[j & M] = hh.nm; N.cx[j & M] = hh.nx;
+            const Cell u{hh.s > NEGH ? hh.s + (int32_t)(j - lo) * E : NEG, hh.nm, hh.nx};
+            run = cmax_left(run, u);
+        }
+        // pass 2: exclusive max-plus scan of the chunk aggregates over the workgroup (ties to the left)
+        const Cell winc = wave_incl_maxscan(run);
+        if (lane == 63) s_scan[wave] = winc;
+        __syncthreads();
+        Cell acc{NEG, 0, 0};
+        for (uint32_t w = 0; w < wave; w++) acc = cmax_left(acc, s_scan[w]);
+        acc = cmax_left(acc, dpp_cell<0x138, 0xf>(winc));  // best u of every column left of my chunk
+        // pass 3: C = max(H, I), prune, row statistics
+        Best4 rb{NEG, 0xFFFFFFFFu, 0, 0};
+        uint32_t myfirst = 0xFFFFFFFFu, mylast = 0;
+        for (uint32_t j = j0; j < j1; j++) {
+            const Cell hh{N.cs[j & M], N.cm[j & M], N.cx[j & M]};
+            Cell I{NEG, acc.nm, acc.nx};
+            if (acc.s > NEGH) I.s = acc.s - O - (int32_t)(j - lo) * E;
+            const Cell u{hh.s > NEGH ? hh.s + (int32_t)(j - lo) * E : NEG, hh.nm, hh.nx};
+            acc = cmax_left(acc, u);
+            Cell c = hh;  // H preferred over I on ties
+            if (I.s > c.s) c = I;
+            const bool alive = c.s >= thr && c.s > NEGH;
+            N.cs[j & M] = alive ? c.s : NEG; N.cm[j & M] = c.nm; N.cx[j & M] = c.nx;
+            if (!alive) N.ds[j & M] = NEG;
+            if (alive) {
+                if (myfirst == 0xFFFFFFFFu) myfirst = j;
+                mylast = j;
+                if (c.s > rb.s) { rb.s = c.s; rb.j = j; rb.nm = c.nm; rb.nx = c.nx; }
+            }
+        }
+        // workgroup reductions: first / last live column, best cell (smallest column on ties: chunks grow with tid)
+        uint32_t wf = myfirst, wl = (myfirst == 0xFFFFFFFFu) ? 0u : mylast + 1u;  // last + 1 so that 0 = none
+        for (int o = 32; o > 0; o >>= 1) { wf = min(wf, (uint32_t)__shfl_xor((int)wf, o)); wl = max(wl, (uint32_t)__shfl_xor((int)wl, o)); }
+        const Best4 wb4 = wave_best(rb);
+        if (lane == 0) { s_first[wave] = wf; s_last[wave] = wl; s_best[wave] = wb4; }
+        __syncthreads();
+        uint32_t first_alive = 0xFFFFFFFFu, last1 = 0;
+        Best4 tb{NEG, 0xFFFFFFFFu, 0, 0};
+        for (int w = 0; w < ANY_THREADS / 64; w++) {
+            first_alive = min(first_alive, s_first[w]);
+            last1 = max(last1, s_last[w]);
+            const Best4 o = s_best[w];
+            if (o.s > tb.s || (o.s == tb.s && o.j < tb.j)) tb = o;
+        }
+        __syncthreads();  // the LDS arrays are rewritten in the next row
+        if (first_alive == 0xFFFFFFFFu) break;
+        lo = first_alive;
+        hi = last1 - 1u;
+        best.maxcols = max(best.maxcols, hi - lo + 1u);
+        best.rows = i;
+        if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.nm; best.nx = tb.nx; }
+    }
+    best.overflow = overflow ? 1u : 0u;
+    if (tid == 0) res[job.slot] = best;
 }
 
 // one wave per group: finalise anchors in rank order as far as DP results exist
@@ -799,7 +942,7 @@ __global__ void k6_finish(Group *__restrict__ groups, uint32_t ngroups, mimeo_al
     G.naln = k;
 }
 
-static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt, g_astate;
+static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt, g_astate, g_ovf_list, g_any;
 
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln) {
@@ -819,13 +962,14 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         if ((rc = g_astate.reserve((size_t)nhsps * 2))) return rc;  // state | defer count
         HIP_TRY(hipMemsetAsync(g_astate.p, 0, (size_t)nhsps * 2, st));
         if ((rc = g_cnt.reserve(16))) return rc;
+        if ((rc = g_ovf_list.reserve((size_t)ngroups * bmax * 2 * sizeof(unsigned int)))) return rc;
         hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups, ANCHOR_SPLIT), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups,
                            d_sorted, d_order, (unsigned long long *)g_packed.p);
         hipLaunchKernelGGL(k6_anchor_final, dim3(ngroups), dim3(256), 0, st, (const Group *)d_groups, d_sorted, d_order,
                            (const unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);
         for (;;) {
-            HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 8, st));
-            unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1;
+            HIP_TRY(hipMemsetAsync(g_cnt.p, 0, 16, st));
+            unsigned int *njobs = (unsigned int *)g_cnt.p, *remaining = njobs + 1, *novf = njobs + 2;
             hipLaunchKernelGGL(k6_pick, dim3(ngroups), dim3(64), 0, st, d_groups, (const uint2 *)g_anchors.p,
                                (const mimeo_alignment *)d_aln, bmax, (uint8_t *)g_astate.p, (uint8_t *)g_astate.p + nhsps,
                                (DpJob *)g_jobs.p, njobs);
@@ -841,7 +985,20 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                 hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
                                    (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0);
                 hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
-                                   (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+                                   (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, novf,
+                                   (unsigned int *)g_ovf_list.p);
+                // bands beyond 2048 columns (tandem arrays): the global-memory kernel, a few jobs at a time
+                unsigned int nov = 0;
+                HIP_TRY(hipMemcpyAsync(&nov, novf, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (nov) {
+                    const unsigned int slots = std::min<unsigned int>(nov, 32u);
+                    if ((rc = g_any.reserve((size_t)slots * ANY_SLOT_WORDS * 4))) return rc;
+                    for (unsigned int f = 0; f < nov; f += slots)
+                        hipLaunchKernelGGL(k6_dp_any, dim3(std::min(slots, nov - f)), dim3(ANY_THREADS), 0, st, (const Group *)d_groups,
+                                           (const DpJob *)g_jobs.p, (const unsigned int *)g_ovf_list.p, f, (HalfResult *)g_res.p,
+                                           (uint32_t *)g_any.p, p->gap_open, p->gap_extend, p->ydrop);
+                }
             }
             if (getenv("MIMEO_K6_STATS") && h[0]) {
                 std::vector<DpJob> hj(h[0]);

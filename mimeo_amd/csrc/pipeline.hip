@@ -238,7 +238,7 @@ static BatchResult run_batch(Batch &b, const mimeo_params *p, std::vector<std::v
     for (size_t gi = 0; gi < b.groups.size(); gi++) {
         const Group &g = b.groups[gi];
         if (g.overflow) {
-            set_error("gapped extension: DP band wider than 2048 columns, or score beyond int32: not supported yet");
+            set_error("gapped extension: DP band wider than 65536 columns, or score beyond int32: not supported");
             return fail(MIMEO_ERR_LIMIT);
         }
         r.chained += g.nchain;

@@ -105,18 +105,43 @@ def test_align_with_n_and_lowercase(eng):
     g.close()
 
 
-def test_wide_band_second_chance_and_limit(eng):
-    """A large y-drop widens the DP band past the 1024-column register window: the 2048-column kernel
-    must take over with identical results; past 2048 columns the call fails loudly (no truncation)."""
+def test_wide_bands_all_kernels(eng):
+    """A large y-drop widens the DP band past the 1024-column register window (the 2048-column kernel takes over)
+    and then past 2048 columns (the global-memory kernel takes over): identical results each time."""
     from oracle import oracle as O
     names, seqs = synth_genome(97, 120_000, 2, repeat_frac=0.2, families=2, cons_len=(800, 2000), max_div=0.1)
     g = eng.Genome(names, seqs)
-    got = eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=25000))
-    exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes(), O.default_params(ydrop=25000))
-    assert exp.size > 2
-    _cmp(got, exp, 'wide', ordered=True)
-    with pytest.raises(RuntimeError, match='band'):
-        eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=90000))
+    for yd in (25000, 90000):
+        got = eng.align_pair(g, 0, g, 1, eng.default_params(ydrop=yd))
+        exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes(), O.default_params(ydrop=yd))
+        assert exp.size > 2
+        _cmp(got, exp, ('wide', yd), ordered=True)
+    g.close()
+
+
+def test_tandem_arrays_default_parameters(eng):
+    """Tandem arrays make the live band as wide as the array (every shift by a period scores almost as well):
+    with the DEFAULT parameters the register kernels overflow and the global-memory DP must produce exactly the
+    oracle's alignments."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+
+    def array(unit, n, div):
+        a = np.tile(unit, n)
+        m = rng.random(a.size) < div
+        a[m] = (a[m] + rng.integers(1, 4, int(m.sum()))) & 3
+        return a
+    u1, u2 = rng.integers(0, 4, 7), rng.integers(0, 4, 31)
+    T = acgt[np.concatenate([rng.integers(0, 4, 4000), array(u1, 700, 0.03), rng.integers(0, 4, 3000), array(u2, 150, 0.05),
+                             rng.integers(0, 4, 4000)])]
+    Q = acgt[np.concatenate([rng.integers(0, 4, 2000), array(u2, 120, 0.05), rng.integers(0, 4, 5000), array(u1, 600, 0.03),
+                             rng.integers(0, 4, 2500)])]
+    g = eng.Genome(['t', 'q'], [T, Q])
+    got = eng.align_pair(g, 0, g, 1)
+    exp = O.align_pair(T.tobytes(), Q.tobytes())
+    assert exp.size >= 2
+    _cmp(got, exp, 'tandem', ordered=True)
     g.close()
 
 
