@@ -23,7 +23,7 @@ def main():
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
         seed = int(rng.integers(1, 1 << 30))
-        L = int(rng.choice([20_000, 60_000, 150_000, 400_000]))
+        L = int(rng.choice([20_000, 60_000, 150_000, 300_000]))
         fam = int(rng.integers(1, 8))
         names, seqs = synth_genome(seed, 2 * L, 2, repeat_frac=float(rng.choice([0.02, 0.1, 0.3])), families=fam,
                                    cons_len=sorted((int(rng.choice([50, 300, 1500])), int(rng.choice([400, 2500, 8000])))) and (lambda a, b: (min(a, b), max(a, b) + 1))(int(rng.choice([50, 300, 1500])), int(rng.choice([400, 2500, 8000]))),
@@ -55,11 +55,26 @@ def main():
                 if not np.array_equal(np.sort(a[HC], order=HC), np.sort(b[HC], order=HC)):
                     ok = False
                     print('HSP MISMATCH', seed, L, kw, tq, strand, a.size, b.size, flush=True)
+            tg = time.time()
             a = engine.align_pair(g, tq[0], g, tq[1], engine.default_params(**kw))
+            tg = time.time() - tg
+            tc = time.time()
             b = O.align_pair(seqs[tq[0]].tobytes(), seqs[tq[1]].tobytes(), O.default_params(**kw))
+            tc = time.time() - tc
+            if tg > 1.0 or tc > 20.0:
+                print('slow case: gpu %.2f s  oracle %.1f s' % (tg, tc), seed, L, kw, tq, flush=True)
             if not np.array_equal(np.sort(a[COLS], order=COLS), np.sort(b[COLS], order=COLS)):
                 ok = False
                 print('ALIGN MISMATCH', seed, L, kw, tq, a.size, b.size, flush=True)
+            if n % 5 == 0 and L <= 60_000:  # the multi-unit pipeline (lanes, batches) against per-pair oracle runs
+                allp = [(0, 0), (0, 1), (1, 0), (1, 1)]
+                aa = engine.align_pairs(g, None, allp, engine.default_params(**kw))
+                for t, q in allp:
+                    e = O.align_pair(seqs[t].tobytes(), seqs[q].tobytes(), O.default_params(**kw))
+                    sub = aa[(aa['tid'] == t) & (aa['qid'] == q)]
+                    if not np.array_equal(np.sort(sub[COLS], order=COLS), np.sort(e[COLS], order=COLS)):
+                        ok = False
+                        print('PAIRS MISMATCH', seed, L, kw, (t, q), sub.size, e.size, flush=True)
         except RuntimeError as e:
             if 'band' in str(e) or 'not supported' in str(e):
                 print('limit', seed, L, kw, str(e)[:80], flush=True)
