@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — mimeo-self hot path on synthetic genomes (BASELINE.json metric: Gbp-aligned/s).
 
-A "step" = one pass of the hot path over the whole workload: seed index build, seed scan,
-gap-free extension, chain, gapped extension for every ordered scaffold pair x 2 strands, then
-the A11 filter and the coverage-depth collapse — i.e. everything run_jobs.sh does in the
-reference (src/mimeo/wrappers.py:1015-1177), with the packed genome already resident in HBM.
+Default workload = the configuration BASELINE.json's metric is quoted on: C4, `mimeo self` on a 1 Gbp
+synthetic genome (100 scaffolds x 10 Mbp, 5 % planted repeats, seed 1000), --minIdt 80 --minLen 100
+--minCov 3.  It fits one GPU (packed genome 1 GB + 21 GB of seed indexes in 288 GB).
 
-Workload at every N: BASELINE.json configs[1] = C2, `mimeo self` on a 50 Mbp synthetic genome
-(10 scaffolds x 5 Mbp, 5 % planted repeats, seed 50), --minIdt 80 --minLen 100 --minCov 3.
-N > 1 shards the ordered pairs over ranks (contiguous, cost-balanced slices of a block order), gathers the
-alignment records with one all-gatherv over RCCL, and rank 0 filters + collapses: total work is
-fixed, so "scaling" is "strong".
+A "step" (row mode, workloads c4 / c4small) = one TARGET scaffold per rank through the whole hot path:
+the seed indexes of that scaffold are (re)built (both strands), the scaffold is aligned as target against
+all S query scaffolds x 2 strands (seed scan, gap-free extension, chain, gapped extension: 2*S units =
+1/S of the job's S^2 ordered pairs), the A11 filter and the coverage-depth collapse of that target run
+(coverage is per target, src/mimeo/wrappers.py:1131-1150), and the filtered records and regions of all
+ranks are concatenated by an all-gatherv (RCCL).  Rank r takes rows r, r+N, r+2N, ...: S/N steps on N GPUs
+are exactly the job run_jobs.sh does in the reference (wrappers.py:1015-1177), every seed index built once.
+The packed genome and the seed indexes of the other scaffolds are resident in HBM when the timed region
+starts.  Per-GPU work is fixed as N grows: "scaling" is "weak"; value = target bases completed by all ranks
+per second = (1 Gbp genome) / (time the whole job takes at that rate).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|small|c4|c3|c5|c3small|c5small] [--no-cpu-baseline]
+Job mode (workloads c2, small, c3, c5, ...: the other BASELINE configs, development aids): a step is the
+whole job, pairs sharded over ranks, "scaling" "strong" (the round-1 bench line for C2 is kept in profiles/).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4small|c2|small|c3|c5|c3small|c5small] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -26,15 +33,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (mode, seed A, seed B, bp per genome, scaffolds per genome, minIdt, minCov)
-    'c2': ('self', 50, None, 50_000_000, 10, 80, 3),
-    'small': ('self', 50, None, 4_000_000, 4, 80, 3),
-    'c4': ('self', 1000, None, 1_000_000_000, 100, 80, 3),
+    # name: (mode, seed A, seed B, bp per genome, scaffolds per genome, minIdt, minCov, step kind)
+    'c4': ('self', 1000, None, 1_000_000_000, 100, 80, 3, 'row'),
+    'c4small': ('self', 1000, None, 6_000_000, 6, 80, 3, 'row'),   # the row-mode code path at test size
     # the other BASELINE configs, runnable for development (not bench lines; SURVEY §8 sizes)
-    'c3': ('x', 201, 202, 200_000_000, 20, 80, 5),
-    'c3small': ('x', 201, 202, 8_000_000, 4, 80, 5),
-    'c5': ('map', 1001, 1002, 1_000_000_000, 100, 98, 0),
-    'c5small': ('map', 1001, 1002, 8_000_000, 4, 98, 0),
+    'c2': ('self', 50, None, 50_000_000, 10, 80, 3, 'job'),
+    'small': ('self', 50, None, 4_000_000, 4, 80, 3, 'job'),
+    'c3': ('x', 201, 202, 200_000_000, 20, 80, 5, 'job'),
+    'c3small': ('x', 201, 202, 8_000_000, 4, 80, 5, 'job'),
+    'c5': ('map', 1001, 1002, 1_000_000_000, 100, 98, 0, 'job'),
+    'c5small': ('map', 1001, 1002, 8_000_000, 4, 98, 0, 'job'),
 }
 MIN_LEN = 100
 
@@ -61,35 +69,61 @@ def band_order(pairs, nscaf, world):
     return sorted(pairs, key=lambda p: (p[0] // B, p[1], p[0]))
 
 
-def cpu_baseline(names, seqs, self_pair, cross_pair):
-    """The C oracle (a single-thread port of the reference's lastz-driven path, oracle/) timed on a
-    bounded sample of this workload — one (A,A) pair and one (A,B) pair — and extrapolated to the
-    S self pairs and S^2 - S cross pairs of the whole job.  The reference runs its script serially
-    (utils.py:247), so the 1-core figure is the like-for-like one; `allcores` (SURVEY §8d ii) runs one
-    sampled cross pair per host core concurrently, i.e. the rate a pair-parallel CPU job would reach."""
+def row_of(step_no, world, rank, nscaf):
+    """Target scaffold of `rank` in global step `step_no` (row mode): rows are dealt round-robin, so the
+    N ranks of one step hold N different targets and S/N steps cover the job."""
+    return (step_no * world + rank) % nscaf
+
+
+def a11_filter(alns, min_len, min_idt):
+    """The awk filters of wrappers.py:1043-1052 on engine records: length1 = end1 - start1 + 1 >= minLen
+    and the PRINTED one-decimal identity >= minIdt (formats.identity_pct, element-wise)."""
+    if not alns.size:
+        return alns
+    a = alns[alns['tend'].astype(np.int64) - alns['tstart'] >= min_len]
+    d = a['id_d'].astype(np.float64)
+    pct = np.char.mod('%.1f', np.where(d > 0, 100.0 * a['id_n'] / np.maximum(d, 1), 0.0)).astype(np.float64)
+    return a[pct >= min_idt]
+
+
+def cpu_oracle_times(pair_jobs, threads=1):
+    """Wall seconds of the C oracle (oracle/: a single-thread port of the lastz-driven path) on
+    `pair_jobs` = [(target bytes, query bytes)], `threads` of them at a time (ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.lib()
-    times = []
-    for t, q in (self_pair, cross_pair):
-        t0 = time.time()
-        O.align_pair(seqs[t].tobytes(), seqs[q].tobytes())
-        times.append(time.time() - t0)
+    t0 = time.time()
+    if threads <= 1:
+        for t, q in pair_jobs:
+            O.align_pair(t, q)
+    else:
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda pr: O.align_pair(pr[0], pr[1]), pair_jobs))
+    return time.time() - t0
+
+
+def host_cores():
+    # at most 16 threads: the CPU share of a one-GPU box, and it keeps this leg near half a minute
+    return min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+
+
+def cpu_baseline_job(names, seqs, self_pair, cross_pair):
+    """Job mode: the oracle timed on one (A,A) pair and one (A,B) pair and extrapolated to the S self
+    pairs and S^2 - S cross pairs of the whole job.  The reference runs its script serially (utils.py:247),
+    so the 1-core figure is the like-for-like one; `allcores` (SURVEY §8d ii) runs one sampled cross pair
+    per host core concurrently, i.e. the rate a pair-parallel CPU job would reach."""
+    times = [cpu_oracle_times([(seqs[t].tobytes(), seqs[q].tobytes())]) for t, q in (self_pair, cross_pair)]
     S = len(names)
     total_s = S * times[0] + (S * S - S) * times[1]
     total_bp = sum(len(s) for s in seqs)
     out = {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
            'sample': 'pairs %d-%d (%.1f s) and %d-%d (%.1f s) of %d ordered pairs; whole job extrapolated as '
                      'S*t_self + (S*S-S)*t_cross = %.0f s' % (self_pair + (times[0],) + cross_pair + (times[1], S * S, total_s))}
-    # at most 16 threads: the CPU share of a one-GPU box, and it keeps this leg near half a minute
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    cores = host_cores()
     if cores > 1 and S > 1:
         sample = [(t, q) for t in range(S) for q in range(S) if t != q][:cores]
         bufs = [seqs[i].tobytes() for i in range(S)]
-        t0 = time.time()
-        with ThreadPoolExecutor(len(sample)) as ex:  # ctypes drops the GIL inside the C call
-            list(ex.map(lambda pr: O.align_pair(bufs[pr[0]], bufs[pr[1]]), sample))
-        wall = time.time() - t0
+        wall = cpu_oracle_times([(bufs[t], bufs[q]) for t, q in sample], threads=len(sample))
         per_pair = wall / len(sample)  # effective seconds per cross pair with all cores busy
         mt_s = (S * S - S) * per_pair + S * times[0] / min(cores, S)
         out['allcores'] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': len(sample), 'kind': 'port',
@@ -98,14 +132,41 @@ def cpu_baseline(names, seqs, self_pair, cross_pair):
     return out
 
 
+def cpu_baseline_rows(seqs, slice_bp=2_000_000):
+    """Row mode (C4): a whole 10 Mbp x 10 Mbp pair takes the oracle about a minute, so the bounded sample
+    is target scaffold 0 against the first `slice_bp` bases of scaffold 1 (both strands); seed hits, and
+    with them the time, grow with Lt x Lq, so one ordered pair costs Lq/slice_bp times that and the job
+    S^2 pairs (the S self pairs are priced as cross pairs)."""
+    S, L = len(seqs), len(seqs[0])
+    sl = min(slice_bp, L)
+    t_buf = seqs[0].tobytes()
+    one = cpu_oracle_times([(t_buf, seqs[1][:sl].tobytes())])
+    total_s = one * (L / sl) * S * S
+    total_bp = S * L
+    out = {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
+           'sample': 'scaffold 0 (%.1f Mbp) x first %.1f Mbp of scaffold 1, both strands: %.1f s; whole job (%d ordered pairs) '
+                     'extrapolated as t * (Lq / slice) * S^2 = %.0f s' % (L / 1e6, sl / 1e6, one, S * S, total_s)}
+    cores = host_cores()
+    if cores > 1:
+        jobs = [(t_buf, seqs[1 + k % (S - 1)][(k // (S - 1)) * sl:(k // (S - 1) + 1) * sl].tobytes()) for k in range(cores)]
+        wall = cpu_oracle_times(jobs, threads=cores)
+        mt_s = (wall / cores) * (L / sl) * S * S
+        out['allcores'] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': cores, 'kind': 'port',
+                           'sample': '%d such slices run concurrently on %d threads in %.1f s; whole job extrapolated to %.0f s'
+                                     % (cores, cores, wall, mt_s)}
+    return out
+
+
 def pmc_traffic(workload):
     """HBM bytes per seed-scan launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 correction, calibrated on k3_join_count; profiles/r01_pmc_seed_scan.json).  Only C2 was measured."""
-    if workload != 'c2':
+    gfx950 correction, calibrated on k3_join_count; profiles/r01_pmc_seed_scan.json)."""
+    key = {'c2': 'c2', 'c4': 'c4'}.get(workload)
+    if key is None:
         return None
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_seed_scan.json')) as f:
-            return json.load(f)['k3_join_fill']['corrected_bytes_per_launch_cross_unit']
+            d = json.load(f)['k3_join_fill']
+        return d['corrected_bytes_per_launch_cross_unit' if key == 'c2' else 'corrected_bytes_per_launch_c4_unit']
     except Exception:
         return None
 
@@ -113,14 +174,14 @@ def pmc_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--emulate', default=None, help='R/N: time the shard rank R of N would get, on this one GPU, without communication (development aid)')
+    ap.add_argument('--emulate', default=None, help='job mode, R/N: time the shard rank R of N would get, on this one GPU, without communication (development aid)')
     args = ap.parse_args()
 
-    from mimeo_amd import _ffi, engine, formats, workflow
+    from mimeo_amd import _ffi, engine, workflow
     from mimeo_amd.dist import Dist
     from mimeo_amd.synth import make_families, synth_genome
 
@@ -129,7 +190,7 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, dist.world), file=sys.stderr)
     # MIMEO_FORCE_DEVICE lets several ranks share one GPU (rehearsing the N>1 path on a 1-GPU box)
     engine.init(int(os.environ.get('MIMEO_FORCE_DEVICE', dist.local_rank)))
-    mode, seed, seed_b, total_bp, nscaf, MIN_IDT, MIN_COV = WORKLOADS[args.workload]
+    mode, seed, seed_b, total_bp, nscaf, MIN_IDT, MIN_COV, kind = WORKLOADS[args.workload]
     B = None
     if mode == 'self':
         names, seqs = synth_genome(seed, total_bp, nscaf)
@@ -143,32 +204,51 @@ def main():
     pairs = workflow.all_pairs(nscaf, nscaf if B is not None else None)
     L = A.lengths
     LQ = B.lengths if B is not None else L
-    ew, er = (int(args.emulate.split('/')[1]), int(args.emulate.split('/')[0])) if args.emulate else (dist.world, dist.rank)
-    mine = split_contiguous(band_order(pairs, nscaf, ew), lambda p: L[p[0]] * LQ[p[1]] * (1.3 if B is None and p[0] == p[1] else 1.0), ew, er)
     params = engine.default_params()
     names_sorted = sorted(names, key=lambda s: s.encode())
-    cid = {n: i for i, n in enumerate(names_sorted)}
+    cid_of_tid = np.array([names_sorted.index(n) for n in names], dtype=np.uint32)  # chrom id = rank in C-locale name order
     lens_sorted = [L[names.index(n)] for n in names_sorted]
+    step_no = [0]
 
-    def step():
+    if kind == 'row':
+        A.build_indexes()  # resident like the packed genome; every step rebuilds its own target's two
+        mine = None
+    else:
+        ew, er = (int(args.emulate.split('/')[1]), int(args.emulate.split('/')[0])) if args.emulate else (dist.world, dist.rank)
+        mine = split_contiguous(band_order(pairs, nscaf, ew), lambda p: L[p[0]] * LQ[p[1]] * (1.3 if B is None and p[0] == p[1] else 1.0), ew, er)
+
+    def intervals_of(a):
+        iv = np.zeros(a.size, dtype=_ffi.INTERVAL)
+        if a.size:
+            iv['chrom'], iv['start'], iv['end'] = cid_of_tid[a['tid']], a['tstart'] + 1, a['tend']
+        return iv
+
+    def step_row():
+        """One target scaffold per rank: indexes of that scaffold, 2*S units, A11 filter, collapse, gather."""
+        t = row_of(step_no[0], dist.world, dist.rank, nscaf)
+        step_no[0] += 1
+        A.drop_indexes([t])
+        alns = engine.align_pairs(A, None, [(t, q) for q in range(nscaf)], params)
+        st = engine.stats()
+        a = a11_filter(alns, MIN_LEN, MIN_IDT)
+        regions = engine.coverage_collapse(intervals_of(a), lens_sorted, MIN_COV, MIN_LEN)
+        return st, dist.allgather_records(a), dist.allgather_records(regions)
+
+    def step_job():
         alns = engine.align_pairs(A, B, mine, params) if mine else np.zeros(0, dtype=_ffi.ALIGNMENT)
         st = engine.stats()
         alns = dist.allgather_records(alns)
         regions = None
         if dist.rank == 0:
-            # A11 filter (length1 >= minLen, printed identity >= minIdt) and BED projection
-            ln = alns['tend'].astype(np.int64) - alns['tstart']
-            keep = ln >= MIN_LEN
-            pct = np.array([float(formats.identity_pct(int(n), int(d))) for n, d in zip(alns['id_n'][keep], alns['id_d'][keep])])
-            a = alns[keep][pct >= MIN_IDT]
-            iv = np.stack([np.array([cid[names[t]] for t in a['tid']], dtype=np.uint32).reshape(-1),
-                           a['tstart'] + 1, a['tend']], 1).astype(np.uint32) if a.size else np.zeros((0, 3), np.uint32)
+            a = a11_filter(alns, MIN_LEN, MIN_IDT)
             if mode == 'map':  # A16 has no collapse; the tandem scorer (K8) filters the target slices instead
                 m = engine.tandem_masked(A, np.stack([a['tid'], a['tstart'] + 1, a['tend']], 1).astype(np.uint32)) if a.size else np.zeros(0, np.uint32)
                 regions = a[m.astype(np.float64) * 100 < 40.0 * (a['tend'] - a['tstart'] - 1).clip(1)] if a.size else a
             else:
-                regions = engine.coverage_collapse(iv, lens_sorted, MIN_COV, MIN_LEN)
+                regions = engine.coverage_collapse(intervals_of(a), lens_sorted, MIN_COV, MIN_LEN)
         return st, alns, regions
+
+    step = step_row if kind == 'row' else step_job
 
     import torch
     def sync():
@@ -180,36 +260,58 @@ def main():
         step()
     sync()
     t0 = time.time()
+    agg = {}
+    n_aln = n_reg = 0
     for _ in range(args.steps):
         st, alns, regions = step()
+        for k, v in st.items():
+            agg[k] = agg.get(k, 0) + v
+        n_aln += int(alns.size)
+        n_reg += int(regions.size) if regions is not None else 0
     sync()
     dt = dist.max_float(time.time() - t0)
     ms_per_step = 1000.0 * dt / max(1, args.steps)
 
     if dist.rank == 0:
-        launches = max(1, st['scan_launches'])
-        t_fill = st['ms_scan_fill'] / 1e3 / launches          # s per seed-scan (fill) launch, HIP events
-        b_alg = st['scan_bytes_algorithmic'] / launches        # SURVEY §8(d) B_scan per launch
+        launches = max(1, agg['scan_launches'])
+        t_fill = agg['ms_scan_fill'] / 1e3 / launches          # s per seed-scan (fill) launch, HIP events
+        b_alg = agg['scan_bytes_algorithmic'] / launches        # SURVEY §8(d) B_scan per launch
         achieved = b_alg / t_fill / 1e9 if t_fill > 0 else 0.0
+        scaf_mbp = total_bp / nscaf / 1e6
+        if kind == 'row':
+            # target bases completed by all ranks per second; S/N such steps are the whole job
+            value = dist.world * (total_bp / nscaf) / 1e9 / (ms_per_step / 1e3)
+            what = ('a step = one target scaffold per rank x all %d query scaffolds x 2 strands (%d units = 1/%d of the %d ordered pairs), '
+                    'its seed indexes rebuilt, A11 filter + coverage collapse of that target, records all-gathered; rows dealt round-robin'
+                    % (nscaf, 2 * nscaf, nscaf, len(pairs)))
+            par = 'target rows x%d (no data-path collective; all-gatherv of records)' % dist.world
+        else:
+            value = total_bp / 1e9 / (ms_per_step / 1e3)
+            what = 'a step = the whole job (%d ordered pairs)' % len(pairs)
+            par = 'pairs-sharded x%d' % dist.world
         line = {
-            'metric': 'Gbp-aligned/sec (mimeo %s, --minIdt %d --minLen %d%s)' % (mode, MIN_IDT, MIN_LEN, ' --minCov %d' % MIN_COV if MIN_COV else ' --maxtandem 40'),
-            'value': total_bp / 1e9 / (ms_per_step / 1e3), 'unit': 'Gbp-aligned/s',
+            'metric': 'Gbp-aligned/sec (mimeo %s, %s genome, --minIdt %d --minLen %d%s)'
+                      % (mode, '%g Gbp' % (total_bp / 1e9) if total_bp >= 1e9 else '%d Mbp' % (total_bp // 1_000_000), MIN_IDT, MIN_LEN,
+                         ' --minCov %d' % MIN_COV if MIN_COV else ' --maxtandem 40'),
+            'value': value, 'unit': 'Gbp-aligned/s',
             'n_gpus': dist.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
-            'config': {'workload': '%s: mimeo-%s, %d Mbp synthetic genome%s, %d scaffolds x %.1f Mbp, 5%% planted repeats, seed %s'
+            'higher_is_better': True, 'scaling': 'weak' if kind == 'row' else 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
+            'config': {'workload': '%s: mimeo-%s, %d Mbp synthetic genome%s, %d scaffolds x %.1f Mbp, 5%% planted repeats, seed %s; %s'
                                    % (args.workload.upper(), mode, total_bp // 1_000_000, '' if B is None else ' x2 (A, B)', nscaf,
-                                      total_bp / nscaf / 1e6, seed if B is None else '%d/%d' % (seed, seed_b)),
-                       'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': 'pairs-sharded x%d' % dist.world},
+                                      scaf_mbp, seed if B is None else '%d/%d' % (seed, seed_b), what),
+                       'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': par},
             'roofline': {'kernel': 'k3_join_fill (seed scan)', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': pmc_traffic(args.workload), 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_seed_scan.json)',
-                         'kernel_bytes_per_launch': st['scan_bytes_kernel'] / launches,
-                         'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3},
-            'stage_ms_rank0': {k: round(st[k], 3) for k in ('ms_index', 'ms_scan', 'ms_scan_fill', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_total')},
-            'counts_rank0': {k: int(st[k]) for k in ('seed_hits', 'hsps', 'chained_hsps', 'alignments')},
-            'result': {'alignments': int(alns.size), 'regions': int(regions.size)},
+                         'kernel_bytes_per_launch': agg['scan_bytes_kernel'] / launches,
+                         'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches)},
+            'stage_ms_per_step_rank0': {k: round(agg[k] / max(1, args.steps), 3) for k in ('ms_index', 'ms_scan', 'ms_scan_fill', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_total')},
+            'counts_per_step_rank0': {k: int(agg[k] // max(1, args.steps)) for k in ('seed_hits', 'hsps', 'chained_hsps', 'alignments')},
+            'result': ({'records_kept': n_aln, 'regions': n_reg} if kind == 'row' else {'alignments': int(alns.size), 'regions': int(regions.size)}),
         }
+        if kind == 'row':
+            line['whole_job_s_at_this_rate'] = total_bp / 1e9 / value
         if not args.no_cpu_baseline and dist.world == 1 and B is None:
-            line['cpu_baseline'] = cpu_baseline(names, seqs, (0, 0), (0, 1))
+            line['cpu_baseline'] = cpu_baseline_rows(seqs) if kind == 'row' and nscaf > 1 else cpu_baseline_job(names, seqs, (0, 0), (0, 1))
         print(json.dumps(line))
     A.close()
     if B is not None:

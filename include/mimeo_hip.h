@@ -181,6 +181,23 @@ int mimeo_genome_load_fasta(const char *const *paths, uint32_t npaths, const cha
                             mimeo_genome **out);
 int mimeo_genome_name(const mimeo_genome *g, uint32_t scaf, const char **name);
 
+/*
+ * Seed-index residency.  lastz rebuilds the target's seed table in every one of the S^2 runs
+ * of run_jobs.sh (call site wrappers.py:1028-1031); mimeo_align_pairs builds the index of a
+ * scaffold strand once per call and, by default, gives it back when the call returns.  With
+ * keep != 0 the indexes that later calls build for scaffolds of `g` stay attached to the handle
+ * (64 MiB + 4 bytes per base and strand: a 1 Gbp genome, both strands, is 21 GB of the 288 GB)
+ * and are reused by every later call, so a job may be issued as several calls (one per target
+ * scaffold, say) without paying for the tables again.  mimeo_genome_drop_indexes releases the
+ * indexes (both strands) of the listed scaffolds, or all of them when n == 0;
+ * mimeo_genome_destroy releases them too.  Results never depend on this setting.
+ */
+int mimeo_genome_keep_indexes(mimeo_genome *g, int keep);
+/* Build (and keep: implies keep != 0) the indexes of the listed scaffolds now — both strands, and the
+ * soft-mask-aware target variant where the scaffold has lower-case bases; n == 0: every scaffold. */
+int mimeo_genome_build_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n);
+int mimeo_genome_drop_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n);
+
 /* ---- stage entry points (parity tests, profiling) ----------------------------- */
 
 /*

@@ -17,6 +17,7 @@ SYMBOLS = [
     'mimeo_get_stats', 'mimeo_free', 'mimeo_genome_create', 'mimeo_genome_destroy', 'mimeo_genome_nscaf',
     'mimeo_genome_length', 'mimeo_seed_hits', 'mimeo_ungapped_hsps', 'mimeo_align_pair', 'mimeo_align_pairs',
     'mimeo_coverage_collapse', 'mimeo_tandem_masked', 'mimeo_genome_load_fasta', 'mimeo_genome_name',
+    'mimeo_genome_keep_indexes', 'mimeo_genome_drop_indexes', 'mimeo_genome_build_indexes',
 ]
 
 
@@ -71,6 +72,9 @@ def load():
     lib.mimeo_genome_length.argtypes = [vp, u32, C.POINTER(u64)]
     lib.mimeo_genome_load_fasta.argtypes = [C.POINTER(C.c_char_p), u32, C.c_char_p, C.POINTER(vp)]
     lib.mimeo_genome_name.argtypes = [vp, u32, C.POINTER(C.c_char_p)]
+    lib.mimeo_genome_keep_indexes.argtypes = [vp, C.c_int]
+    lib.mimeo_genome_drop_indexes.argtypes = [vp, vp, u64]
+    lib.mimeo_genome_build_indexes.argtypes = [vp, vp, u64]
     for name in ('mimeo_seed_hits', 'mimeo_ungapped_hsps'):
         if hasattr(lib, name):
             getattr(lib, name).argtypes = [vp, u32, vp, u32, u32, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]

@@ -124,8 +124,39 @@ int mimeo_genome_create(uint32_t nscaf, const uint8_t *bases, const uint64_t *of
 
 void mimeo_genome_destroy(mimeo_genome *g) {
     if (!g) return;
+    for (auto &kv : g->kept) kv.second.release();
+    g->kept.clear();
     for (auto &s : g->scaf) free_scaffold(s);
     delete g;
+}
+
+int mimeo_genome_keep_indexes(mimeo_genome *g, int keep) {
+    if (!g) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    g->keep_indexes = keep != 0;
+    return MIMEO_OK;
+}
+
+int mimeo_genome_build_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!g || (n && !scaf)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    for (uint64_t i = 0; i < n; i++)
+        if (scaf[i] >= g->scaf.size()) { set_error("bad scaffold id"); return MIMEO_ERR_ARG; }
+    g->keep_indexes = true;
+    return build_kept_indexes(g, scaf, n);
+}
+
+int mimeo_genome_drop_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n) {
+    if (!g || (n && !scaf)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    for (uint64_t i = 0; i < n; i++)
+        if (scaf[i] >= g->scaf.size()) { set_error("bad scaffold id"); return MIMEO_ERR_ARG; }
+    for (auto it = g->kept.begin(); it != g->kept.end();) {
+        bool drop = n == 0;
+        for (uint64_t i = 0; i < n && !drop; i++) drop = std::get<0>(it->first) == scaf[i];
+        if (drop) { it->second.release(); it = g->kept.erase(it); }
+        else ++it;
+    }
+    return MIMEO_OK;
 }
 
 int mimeo_genome_nscaf(const mimeo_genome *g, uint32_t *nscaf) {

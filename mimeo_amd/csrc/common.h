@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <functional>
+#include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -87,6 +89,12 @@ struct Scaffold {
 struct mimeo_genome {
     std::vector<mimeo::Scaffold> scaf;
     std::vector<std::string> names;  // record ids when loaded from FASTA (ingest.hip); else empty
+    // seed indexes kept across mimeo_align_pairs calls (mimeo_genome_keep_indexes); key =
+    // (scaffold number, strand, target-role sv plane in use).  Only touched between calls and by the
+    // calling thread at the start / end of a call.
+    bool keep_indexes = false;
+    mutable std::map<std::tuple<uint32_t, int, int>, mimeo::SeedIndex> kept;
+    bool owns(const mimeo::Scaffold *s) const { return !scaf.empty() && s >= scaf.data() && s < scaf.data() + scaf.size(); }
 };
 
 namespace mimeo {
@@ -204,6 +212,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
 
 void release_pipeline_buffers();  // pipeline.hip
+int build_kept_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n);  // pipeline.hip
 
 // K8: tandem scorer (k8_tandem.hip); host in, host out
 int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch,

@@ -51,10 +51,21 @@ struct IndexCache {
         *sv = (minus ? s.rc : s.fwd).view(tsv);
         return std::make_tuple(&s, minus, tsv ? 1 : 0);
     }
-    void want(const Scaffold &s, int minus, bool as_target, std::set<Key> &seen) {
+    // `owner` is the genome the scaffold belongs to: an index it kept from an earlier call is adopted
+    // instead of being planned (mimeo_genome_keep_indexes)
+    std::map<Key, const mimeo_genome *> owner_of;
+    std::set<Key> adopted;
+    static std::tuple<uint32_t, int, int> kept_key(const mimeo_genome *g, const Key &k) {
+        return std::make_tuple((uint32_t)(std::get<0>(k) - g->scaf.data()), std::get<1>(k), std::get<2>(k));
+    }
+    void want(const mimeo_genome *owner, const Scaffold &s, int minus, bool as_target, std::set<Key> &seen) {
         StrandView sv;
         Key k = key_of(s, minus, as_target, &sv);
-        if (seen.insert(k).second) plan.emplace_back(k, sv);
+        if (!seen.insert(k).second) return;
+        owner_of[k] = owner;
+        auto it = owner->kept.find(kept_key(owner, k));
+        if (it != owner->kept.end()) { m.emplace(k, it->second); adopted.insert(k); }
+        else plan.emplace_back(k, sv);
     }
     void start(hipStream_t st) {
         bstream = st;
@@ -112,9 +123,16 @@ struct IndexCache {
         cv.notify_all();
         if (builder.joinable()) builder.join();
     }
+    // end of a call: indexes go to their genome when it keeps them (also after an error: they are
+    // complete), else back to the pool
     void clear() {
         finish();
-        for (auto &kv : m) kv.second.release();
+        for (auto &kv : m) {
+            if (adopted.count(kv.first)) continue;  // still owned by the genome
+            const mimeo_genome *g = owner_of[kv.first];
+            if (g && g->keep_indexes) g->kept.emplace(kept_key(g, kv.first), kv.second);
+            else kv.second.release();
+        }
         m.clear();
     }
 };
@@ -421,8 +439,8 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     {
         std::set<IndexCache::Key> seen;
         for (const Unit &u : units) {
-            cache.want(A->scaf[u.tid], 0, true, seen);
-            cache.want(QG->scaf[u.qid], (int)u.minus, false, seen);
+            cache.want(A, A->scaf[u.tid], 0, true, seen);
+            cache.want(QG, QG->scaf[u.qid], (int)u.minus, false, seen);
         }
     }
     float ms_chain = 0, ms_gapped = 0;
@@ -473,6 +491,26 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     g_stats.ms_chain = ms_chain;
     g_stats.ms_gapped = ms_gapped;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int build_kept_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n) {
+    const uint64_t cnt = n ? n : g->scaf.size();
+    for (uint64_t i = 0; i < cnt; i++) {
+        const uint32_t id = n ? scaf[i] : (uint32_t)i;
+        const Scaffold &s = g->scaf[id];
+        for (int role = 0; role < 3; role++) {  // query +, query -, target + (only when it differs)
+            StrandView sv;
+            IndexCache::Key k = IndexCache::key_of(s, role == 1, role == 2, &sv);
+            auto kk = std::make_tuple(id, std::get<1>(k), std::get<2>(k));
+            if (g->kept.count(kk)) continue;
+            SeedIndex idx;
+            int rc = build_index(sv, idx, nullptr);
+            if (rc) return rc;
+            g->kept.emplace(kk, idx);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(stream()));
     return 0;
 }
 

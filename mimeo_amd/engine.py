@@ -75,6 +75,25 @@ class Genome:
             self.lengths.append(int(ln.value))
         return self
 
+    def keep_indexes(self, keep=True):
+        """Seed indexes built by later align_pairs calls stay attached to this genome and are reused
+        (lastz rebuilds the table in every run, wrappers.py:1028-1031); results do not change."""
+        _ffi.check(_ffi.load().mimeo_genome_keep_indexes(self._h, 1 if keep else 0))
+
+    def build_indexes(self, scaffolds=None):
+        """Build and keep the seed indexes of the listed scaffolds now (None = all)."""
+        ids = np.ascontiguousarray([] if scaffolds is None else list(scaffolds), dtype=np.uint32)
+        if scaffolds is not None and ids.size == 0:
+            return
+        _ffi.check(_ffi.load().mimeo_genome_build_indexes(self._h, ids.ctypes.data if ids.size else None, ids.size))
+
+    def drop_indexes(self, scaffolds=None):
+        """Release the kept seed indexes (both strands) of the listed scaffolds; None = all."""
+        ids = np.ascontiguousarray([] if scaffolds is None else list(scaffolds), dtype=np.uint32)
+        if scaffolds is not None and ids.size == 0:
+            return
+        _ffi.check(_ffi.load().mimeo_genome_drop_indexes(self._h, ids.ctypes.data if ids.size else None, ids.size))
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             _ffi.load().mimeo_genome_destroy(self._h)

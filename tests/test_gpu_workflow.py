@@ -146,6 +146,34 @@ def test_bench_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     assert b['config']['pair_strands_rank0'] < a['config']['pair_strands_rank0']
 
 
+def test_bench_row_mode_two_ranks_cover_the_same_rows(tmp_path):
+    """Row mode (the default C4 bench line, here at test size): 6 steps of one rank and 3 steps of two
+    ranks (gloo, sharing GPU 0) are the same six target rows — same records kept, same regions — and the
+    line says weak scaling with twice the per-step value basis."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, 'bench.py', '--workload', 'c4small', '--steps', '6', '--warmup', '0', '--no-cpu-baseline'],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().split('\n')[-1])
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MIMEO_DIST_BACKEND='gloo', MIMEO_FORCE_DEVICE='0')
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), 'bench.py', '--gpus', '2', '--workload', 'c4small', '--steps', '3', '--warmup', '0'],
+                         cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = json.loads([l for l in two.stdout.strip().split('\n') if l.startswith('{')][-1])
+    assert a['scaling'] == b['scaling'] == 'weak' and b['n_gpus'] == 2
+    assert a['result']['records_kept'] > 0 and a['result']['regions'] > 0
+    assert b['result'] == a['result']
+    assert a['config']['pair_strands_rank0'] == b['config']['pair_strands_rank0'] == 12
+    # every step rebuilt the indexes of its target (two strands), nothing else
+    assert 0 < a['stage_ms_per_step_rank0']['ms_index'] < 0.5 * a['stage_ms_per_step_rank0']['ms_total']
+
+
 def test_bench_under_rccl_single_rank(tmp_path):
     """The collectives of the N>1 path through the real RCCL backend: one rank under torchrun with
     MIMEO_DIST_FORCE=1 (two ranks cannot share a GPU under RCCL).  Device tensors, all_gather of
@@ -218,3 +246,39 @@ def test_pipeline_modes_give_identical_alignments(tmp_path):
         outs[tag] = r.stdout.strip().split('\n')[-1]
     assert len(set(outs.values())) == 1, outs
     assert int(outs['default'].split()[0]) > 10
+
+
+def test_kept_seed_indexes_are_reused_and_change_nothing(eng):
+    """mimeo_genome_keep_indexes: a job issued row by row (one call per target scaffold) gives the
+    records of the single call, later calls build nothing, dropped scaffolds are rebuilt."""
+    from mimeo_amd import workflow
+    names, seqs = synth_genome(77, 400_000, 4, repeat_frac=0.2, families=3, cons_len=(300, 1500), max_div=0.1)
+    seqs[2][1000:3000] = np.frombuffer(bytes(seqs[2][1000:3000]).lower(), dtype=np.uint8)  # a soft-masked target (own sv plane)
+    A = eng.Genome(names, seqs)
+    pairs = workflow.all_pairs(4)
+    whole = eng.align_pairs(A, None, pairs)
+    built_whole = eng.stats()['ms_index']
+    assert built_whole > 0
+    A.keep_indexes(True)
+    rows = []
+    for t in range(4):
+        rows.append(eng.align_pairs(A, None, [p for p in pairs if p[0] == t]))
+        if t > 0:  # every strand was a query of row 0; only a soft-masked target adds an index of its own
+            assert (eng.stats()['ms_index'] == 0) == (t != 2)
+    got = np.concatenate(rows)
+    assert got.tobytes() == whole.tobytes()
+    A.drop_indexes([1])
+    again = eng.align_pairs(A, None, [p for p in pairs if p[0] == 1])
+    assert eng.stats()['ms_index'] > 0
+    assert again.tobytes() == rows[1].tobytes()
+    A.drop_indexes()
+    A.keep_indexes(False)
+    assert eng.align_pairs(A, None, pairs).tobytes() == whole.tobytes()
+    B = eng.Genome(names[:2], seqs[:2])  # cross-genome: both handles keep their own
+    A.keep_indexes(True); B.keep_indexes(True)
+    x1 = eng.align_pairs(A, B, [(0, 0), (1, 1)])
+    x2 = eng.align_pairs(A, B, [(0, 0), (1, 1)])
+    assert eng.stats()['ms_index'] == 0 and x1.tobytes() == x2.tobytes()
+    with pytest.raises(RuntimeError):
+        A.drop_indexes([99])
+    A.close(); B.close()
