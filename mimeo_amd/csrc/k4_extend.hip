@@ -267,9 +267,13 @@ struct Frame {
     uint32_t dl[6], dh[6], cg[6], nn[6], st[6], sq[6];  // difference / class planes in the target's bit frame
 };
 
+// masks of left window WIN in step order (bit s <-> step 32*WIN + s of the left walk, which starts at the
+// seed end and runs through the seed): difference / class planes, N, and H = "an earlier seed hit of this
+// diagonal ends at the boundary this step reaches"
+struct WinMasks { uint32_t dl, dh, cg, nn, H; };
+
 template <int WIN>
-__device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, const Frame &F, uint32_t bt,
-                                            int transitions, WalkState &L, uint32_t maxl, int xdrop) {
+__device__ __forceinline__ WinMasks left_masks(const Frame &F, uint32_t bt, int transitions) {
     constexpr int b = 1 - WIN;  // word holding seed start - 32*(WIN+1)
     const uint32_t dllo = __builtin_amdgcn_alignbit(F.dl[b + 1], F.dl[b], bt), dlhi = __builtin_amdgcn_alignbit(F.dl[b + 2], F.dl[b + 1], bt);
     const uint32_t dhlo = __builtin_amdgcn_alignbit(F.dh[b + 1], F.dh[b], bt), dhhi = __builtin_amdgcn_alignbit(F.dh[b + 2], F.dh[b + 1], bt);
@@ -287,12 +291,212 @@ __device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, co
     }
     const uint32_t bad = transitions ? (twos | tv) : ones;
     const uint32_t H = ~bad & __builtin_amdgcn_alignbit(F.st[b + 1], F.st[b], bt) & __builtin_amdgcn_alignbit(F.sq[b + 1], F.sq[b], bt);
-    walk_window_pred(tab, L, __brev(__builtin_amdgcn_alignbit(dlhi, dllo, SEED_LEN)), __brev(__builtin_amdgcn_alignbit(dhhi, dhlo, SEED_LEN)),
-                __brev(__builtin_amdgcn_alignbit(cghi, cglo, SEED_LEN)), __brev(__builtin_amdgcn_alignbit(nnhi, nnlo, SEED_LEN)),
-                __brev(H), maxl, xdrop);
+    WinMasks m;
+    m.dl = __brev(__builtin_amdgcn_alignbit(dlhi, dllo, SEED_LEN));
+    m.dh = __brev(__builtin_amdgcn_alignbit(dhhi, dhlo, SEED_LEN));
+    m.cg = __brev(__builtin_amdgcn_alignbit(cghi, cglo, SEED_LEN));
+    m.nn = __brev(__builtin_amdgcn_alignbit(nnhi, nnlo, SEED_LEN));
+    m.H = __brev(H);
+    return m;
 }
 
-template <int VARIANT>  // 1 = production; 2 = loads only, 3 = compute only (timing experiments, wrong results)
+template <int WIN>
+__device__ __forceinline__ void left_window(const uint32_t *__restrict__ tab, const Frame &F, uint32_t bt,
+                                            int transitions, WalkState &L, uint32_t maxl, int xdrop) {
+    const WinMasks m = left_masks<WIN>(F, bt, transitions);
+    walk_window_pred(tab, L, m.dl, m.dh, m.cg, m.nn, m.H, maxl, xdrop);
+}
+
+// the neighbourhood of a hit: six interleaved target words from two words in front of the seed start, seven of
+// the query, brought into the target's bit frame
+__device__ __forceinline__ void load_frame(const StrandView &T, const StrandView &Q, const uint2 h, Frame &F) {
+    const uint32_t bt = h.x & 31u, bq = h.y & 31u, sh = (bq - bt) & 31u;
+    const int32_t wt = (int32_t)(h.x >> 5) - 2, wq = (int32_t)(h.y >> 5) - 2 - (bq < bt ? 1 : 0);
+    uint4 tw[6], qw[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) tw[k] = T.pw[wt + k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) qw[k] = Q.pw[wq + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t qlo = __builtin_amdgcn_alignbit(qw[k + 1].x, qw[k].x, sh), qhi = __builtin_amdgcn_alignbit(qw[k + 1].y, qw[k].y, sh);
+        F.dl[k] = tw[k].x ^ qlo;
+        F.dh[k] = tw[k].y ^ qhi;
+        F.cg[k] = tw[k].x ^ tw[k].y;
+        F.nn[k] = tw[k].z | __builtin_amdgcn_alignbit(qw[k + 1].z, qw[k].z, sh);
+        F.st[k] = T.svt ? T.svt[wt + k] : tw[k].w;
+        F.sq[k] = __builtin_amdgcn_alignbit(qw[k + 1].w, qw[k].w, sh);
+    }
+}
+
+// ---- K4a pre-filter: most seed hits of unrelated sequence are isolated and die at once -------------------
+// A hit can be dropped without walking it when all of this holds inside its frame (64 steps to the left of the
+// seed end, 64 to the right):
+//   * no N, and no earlier seed hit of the diagonal ends at any boundary of the 64 left steps (so whatever the
+//     left walk reaches, the hit is a HEAD: nothing can cover it);
+//   * both walks provably stop inside their 64 steps: at some checkpoint n (a multiple of STEP) the prefix
+//     score U_n is more than xdrop below a lower bound of the prefix score at an earlier checkpoint — the
+//     running best is at least that, so the x-drop rule has fired at or before step n (or the sequence ended:
+//     the zero padding behind a sequence end only adds matches, which loosen both bounds);
+//   * an upper bound of best(left) + best(right) is below hspthresh: the best prefix inside a block is at most
+//     the score at the block's start plus 100 per identical column in it.
+// Such a hit yields nothing: the full walk would classify it as a head, finish both walks inside the frame and
+// find a score below the threshold.  Everything else is queued (per wavefront, in LDS) and walked exactly, 64
+// hits at a time.  Prefix scores come from popcounts of the class masks: with n columns, t transitions
+// (dl=0,dh=1), v transversions (dl=1), a = C/G matches, b = transversions with dh=1 the HOXD70 sum is
+// 91 n + 9 a - 122 t - 205 v - 9 b - 2 c, c = the C<->G transversions among b: U drops the last term (upper
+// bound), the lower bound subtracts 2 b.
+struct Bound {
+    int32_t U, lomax, ub, nb;
+    bool stop;
+};
+// 32 steps of a walk; REV: step s is bit 31 - s of the masks (left windows in position order), else bit s
+template <int STEP, bool REV>
+__device__ __forceinline__ void bound_window(Bound &B, uint32_t mdl, uint32_t mdh, uint32_t mcg, int xdrop) {
+    const uint32_t v = mdl, t = ~mdl & mdh, a = ~(mdl | mdh) & mcg, b = mdl & mdh;
+#pragma unroll
+    for (int j = 0; j < 32 / STEP; j++) {
+        const uint32_t low = (1u << (STEP & 31)) - 1u;
+        const uint32_t bm = REV ? (low << (32 - STEP * (j + 1))) : (low << (STEP * j));
+        const int32_t dv = __popc(v & bm), dt = __popc(t & bm), da = __popc(a & bm), db = __popc(b & bm);
+        B.ub = max(B.ub, B.U + 100 * (STEP - dv - dt));
+        B.U += 91 * STEP + 9 * da - 122 * dt - 205 * dv - 9 * db;
+        B.nb += db;
+        B.stop = B.stop || (B.U + xdrop < B.lomax);
+        B.lomax = max(B.lomax, B.U - 2 * B.nb);
+    }
+}
+
+// left window WIN for the pre-filter: the three score planes in position order (bit 31 = the window's first
+// step) and a SUPERSET of the boundaries that carry an earlier seed hit — eight of the twelve care positions,
+// no seed-validity planes: a false alarm only sends the hit to the exact walk
+constexpr uint32_t CARE8 = 0x2997u;  // offsets 0 1 2 4 7 8 11 13 of CARE19
+struct FilterMasks { uint32_t dl, dh, cg, H; };
+template <int WIN>
+__device__ __forceinline__ FilterMasks filter_left(const Frame &F, uint32_t bt, int transitions) {
+    constexpr int b = 1 - WIN;
+    const uint32_t dllo = __builtin_amdgcn_alignbit(F.dl[b + 1], F.dl[b], bt), dlhi = __builtin_amdgcn_alignbit(F.dl[b + 2], F.dl[b + 1], bt);
+    const uint32_t dhlo = __builtin_amdgcn_alignbit(F.dh[b + 1], F.dh[b], bt), dhhi = __builtin_amdgcn_alignbit(F.dh[b + 2], F.dh[b + 1], bt);
+    const uint32_t cglo = __builtin_amdgcn_alignbit(F.cg[b + 1], F.cg[b], bt), cghi = __builtin_amdgcn_alignbit(F.cg[b + 2], F.cg[b + 1], bt);
+    const uint32_t nlo = dllo | dhlo, nhi = dlhi | dhhi;
+    uint32_t ones = 0, twos = 0, tv = 0;
+#pragma unroll
+    for (int c = 0; c < SEED_LEN; c++) {
+        if (!((CARE8 >> c) & 1u)) continue;
+        const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
+        twos |= ones & v;
+        ones |= v;
+        tv |= c ? __builtin_amdgcn_alignbit(dlhi, dllo, c) : dllo;
+    }
+    FilterMasks m;
+    m.H = ~(transitions ? (twos | tv) : ones);
+    m.dl = __builtin_amdgcn_alignbit(dlhi, dllo, SEED_LEN);
+    m.dh = __builtin_amdgcn_alignbit(dhhi, dhlo, SEED_LEN);
+    m.cg = __builtin_amdgcn_alignbit(cghi, cglo, SEED_LEN);
+    return m;
+}
+
+template <int STEP>
+__device__ __forceinline__ bool hit_needs_walk(const StrandView &T, const StrandView &Q, const uint2 h, int xdrop,
+                                               int hspthresh, int transitions) {
+    Frame F;
+    load_frame(T, Q, h, F);
+    const uint32_t bt = h.x & 31u;
+    const FilterMasks l0 = filter_left<0>(F, bt, transitions), l1 = filter_left<1>(F, bt, transitions);
+    const uint32_t rs = bt + SEED_LEN;
+    Bound L{0, 0, 0, 0, false}, R{0, 0, 0, 0, false};
+    bound_window<STEP, true>(L, l0.dl, l0.dh, l0.cg, xdrop);
+    bound_window<STEP, true>(L, l1.dl, l1.dh, l1.cg, xdrop);
+    bound_window<STEP, false>(R, ext32(F.dl[2], F.dl[3], F.dl[4], rs), ext32(F.dh[2], F.dh[3], F.dh[4], rs),
+                              ext32(F.cg[2], F.cg[3], F.cg[4], rs), xdrop);
+    bound_window<STEP, false>(R, ext32(F.dl[3], F.dl[4], F.dl[5], rs), ext32(F.dh[3], F.dh[4], F.dh[5], rs),
+                              ext32(F.cg[3], F.cg[4], F.cg[5], rs), xdrop);
+    // an N anywhere in the frame (a superset of the 128 steps looked at) or a possible earlier seed hit: exact walk
+    // (no early exit: the test is folded into the result so that nothing has to wait for all thirteen loads)
+    const uint32_t veto = F.nn[0] | F.nn[1] | F.nn[2] | F.nn[3] | F.nn[4] | F.nn[5] | l0.H | l1.H;
+    return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
+}
+
+// first version of the filter (full masks of the exact path): kept for A/B timing (variants 6 / 7)
+template <int STEP>
+__device__ __forceinline__ bool hit_needs_walk_full(const StrandView &T, const StrandView &Q, const uint2 h, int xdrop,
+                                                    int hspthresh, int transitions) {
+    Frame F;
+    load_frame(T, Q, h, F);
+    const uint32_t bt = h.x & 31u;
+    const WinMasks l0 = left_masks<0>(F, bt, transitions), l1 = left_masks<1>(F, bt, transitions);
+    const uint32_t rs = bt + SEED_LEN;
+    const uint32_t r0dl = ext32(F.dl[2], F.dl[3], F.dl[4], rs), r0dh = ext32(F.dh[2], F.dh[3], F.dh[4], rs),
+                   r0cg = ext32(F.cg[2], F.cg[3], F.cg[4], rs), r0nn = ext32(F.nn[2], F.nn[3], F.nn[4], rs);
+    const uint32_t r1dl = ext32(F.dl[3], F.dl[4], F.dl[5], rs), r1dh = ext32(F.dh[3], F.dh[4], F.dh[5], rs),
+                   r1cg = ext32(F.cg[3], F.cg[4], F.cg[5], rs), r1nn = ext32(F.nn[3], F.nn[4], F.nn[5], rs);
+    if (l0.nn | l1.nn | r0nn | r1nn | l0.H | l1.H) return true;
+    Bound L{0, 0, 0, 0, false}, R{0, 0, 0, 0, false};
+    bound_window<STEP, false>(L, l0.dl, l0.dh, l0.cg, xdrop);
+    bound_window<STEP, false>(L, l1.dl, l1.dh, l1.cg, xdrop);
+    bound_window<STEP, false>(R, r0dl, r0dh, r0cg, xdrop);
+    bound_window<STEP, false>(R, r1dl, r1dh, r1cg, xdrop);
+    return !(L.stop && R.stop && L.ub + R.ub < hspthresh);
+}
+
+// the exact walk of one hit from its frame: classifies it (to the generic kernel / follower / candidate)
+template <int VARIANT>
+__device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const StrandView &T, const StrandView &Q,
+                                         const uint2 h, int xdrop, int hspthresh, int transitions, bool &q_med,
+                                         bool &q_fol, bool &q_cd, uint64_t &r_fk, uint32_t &r_fp, Cand &r_cd) {
+    const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
+    const int32_t d = (int32_t)h.x - (int32_t)h.y;
+    const uint32_t bt = h.x & 31u;
+    Frame F;
+    if (VARIANT == 3) {  // compute only (timing experiment, wrong results)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            F.dl[k] = h.x * (k + 1); F.dh[k] = h.y + k; F.cg[k] = h.y * (k + 3); F.nn[k] = 0; F.st[k] = ~0u; F.sq[k] = ~0u;
+        }
+    } else {
+        load_frame(T, Q, h, F);
+    }
+    if (VARIANT == 2) {  // loads only (timing experiment, wrong results)
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc ^= F.dl[k] ^ F.dh[k] ^ F.cg[k] ^ F.nn[k] ^ F.st[k] ^ F.sq[k];
+        if (acc == 0x12345678u) q_med = true;
+        return;
+    }
+    // ---- left walk: up to two windows from the frame (the seed starts at frame bit 64 + bt)
+    WalkState L{0, 0, 0, 0, false, false, 0};
+    const uint32_t maxl = (uint32_t)min(et, eq);
+    left_window<0>(tab, F, bt, transitions, L, maxl, xdrop);
+    if (!L.done) left_window<1>(tab, F, bt, transitions, L, maxl, xdrop);
+    if (!L.done) {  // still alive after 64 bases: generic kernel
+        q_med = true;
+    } else if (L.found) {
+        q_fol = true;
+        r_fk = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
+        r_fp = (uint32_t)et - L.found_step;
+    } else {
+        // ---- right walk: two windows from the frame (frame bit of the seed end = 64 + bt + 19)
+        WalkState R{0, 0, 0, 0, false, false, 0};
+        const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
+        const uint32_t rs = bt + SEED_LEN;
+        walk_window_pred(tab, R, ext32(F.dl[2], F.dl[3], F.dl[4], rs), ext32(F.dh[2], F.dh[3], F.dh[4], rs),
+                         ext32(F.cg[2], F.cg[3], F.cg[4], rs), ext32(F.nn[2], F.nn[3], F.nn[4], rs), 0u, maxr, xdrop);
+        if (!R.done)
+            walk_window_pred(tab, R, ext32(F.dl[3], F.dl[4], F.dl[5], rs), ext32(F.dh[3], F.dh[4], F.dh[5], rs),
+                             ext32(F.cg[3], F.cg[4], F.cg[5], rs), ext32(F.nn[3], F.nn[4], F.nn[5], rs), 0u, maxr, xdrop);
+        if (!R.done) {
+            q_med = true;
+        } else if (L.best + R.best >= hspthresh) {
+            q_cd = true;
+            r_cd = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best};
+        }
+    }
+}
+
+// VARIANT 5 = production: pre-filter with checkpoints every 16 steps; 4 = every 8 steps; 1 = no pre-filter, every hit
+// is walked (the round-1 kernel); 6 / 7 = first version of the filter; 2 = loads only, 3 = compute only (timing
+// experiments, wrong results)
+template <int VARIANT>
 __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
                                                               const uint2 *__restrict__ hits, uint64_t nhits_arg,
                                                               int xdrop, int hspthresh, int transitions,
@@ -302,6 +506,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                                                               uint32_t *__restrict__ fprev,
                                                               uint2 *__restrict__ medq, int skip_diag0,
                                                               const unsigned long long *__restrict__ nhits_dev) {
+    constexpr bool FILTER = VARIANT >= 4 && VARIANT <= 7;
     // speculative launch: the count comes from the seed scan on the device, nhits_arg is the buffer capacity
     // (a count beyond it means the scan wrote nothing: no work)
     uint64_t nhits = nhits_arg;
@@ -313,92 +518,25 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
     __shared__ uint64_t s_fk[FAST_THREADS / 64][QCAP];
     __shared__ uint32_t s_fp[FAST_THREADS / 64][QCAP];
     __shared__ Cand s_cd[FAST_THREADS / 64][QCAP];
+    __shared__ uint2 s_walk[FILTER ? FAST_THREADS / 64 : 1][QCAP];  // hits that passed the pre-filter, per wavefront
     for (int i = threadIdx.x; i < GROUP_TAB; i += FAST_THREADS) tab[i] = group_tab[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_med = 0, n_fol = 0, n_cd = 0;  // wave-uniform fill levels
-    const uint64_t stride = (uint64_t)gridDim.x * FAST_THREADS;
-    for (uint64_t g0 = (uint64_t)blockIdx.x * FAST_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
-        const uint64_t gid = g0 + lane;
+    uint32_t n_med = 0, n_fol = 0, n_cd = 0, n_walk = 0;  // wave-uniform fill levels
+
+    // walk one hit per lane exactly and stage the records; a queue is flushed with one atomic when the new
+    // records would not fit (QCAP = 64 = the most one batch can add); `final` flushes what is left
+    auto walk_batch = [&](bool active, uint2 h, bool final) {
         bool q_med = false, q_fol = false, q_cd = false;
-        uint2 h = make_uint2(0, 0);
         uint64_t r_fk = 0;
         uint32_t r_fp = 0;
         Cand r_cd{0, 0, 0, 0};
-        if (gid < nhits) h = hits[gid];
-        if (gid < nhits && !(skip_diag0 && h.x == h.y)) {  // the main diagonal of a self unit belongs to k4_diag0
-        const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
-        const int32_t d = (int32_t)h.x - (int32_t)h.y;
-        const uint32_t bt = h.x & 31u, bq = h.y & 31u, sh = (bq - bt) & 31u;
-        const int32_t wt = (int32_t)(h.x >> 5) - 2, wq = (int32_t)(h.y >> 5) - 2 - (bq < bt ? 1 : 0);
-        uint4 tw[6], qw[7];
-        if (VARIANT == 3) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) tw[k] = make_uint4(h.x * (k + 1), h.y + k, 0, ~0u);
-#pragma unroll
-            for (int k = 0; k < 7; k++) qw[k] = make_uint4(h.y * (k + 3), h.x + k, 0, ~0u);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; k++) tw[k] = T.pw[wt + k];
-#pragma unroll
-            for (int k = 0; k < 7; k++) qw[k] = Q.pw[wq + k];
-        }
-        if (VARIANT == 2) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) acc ^= tw[k].x ^ tw[k].y ^ tw[k].z ^ tw[k].w ^ qw[k].x ^ qw[k].y ^ qw[k].z ^ qw[k].w;
-            acc ^= qw[6].x ^ qw[6].y ^ qw[6].z ^ qw[6].w;
-            if (acc == 0x12345678u) q_med = true;
-        } else {
-        Frame F;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const uint32_t qlo = __builtin_amdgcn_alignbit(qw[k + 1].x, qw[k].x, sh), qhi = __builtin_amdgcn_alignbit(qw[k + 1].y, qw[k].y, sh);
-            F.dl[k] = tw[k].x ^ qlo;
-            F.dh[k] = tw[k].y ^ qhi;
-            F.cg[k] = tw[k].x ^ tw[k].y;
-            F.nn[k] = tw[k].z | __builtin_amdgcn_alignbit(qw[k + 1].z, qw[k].z, sh);
-            F.st[k] = T.svt ? T.svt[wt + k] : tw[k].w;
-            F.sq[k] = __builtin_amdgcn_alignbit(qw[k + 1].w, qw[k].w, sh);
-        }
-        // ---- left walk: up to two windows from the frame (the seed starts at frame bit 64 + bt)
-        WalkState L{0, 0, 0, 0, false, false, 0};
-        const uint32_t maxl = (uint32_t)min(et, eq);
-        left_window<0>(tab, F, bt, transitions, L, maxl, xdrop);
-        if (!L.done) left_window<1>(tab, F, bt, transitions, L, maxl, xdrop);
-        if (!L.done) {  // still alive after 64 bases: generic kernel
-            q_med = true;
-        } else if (L.found) {
-            q_fol = true;
-            r_fk = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;
-            r_fp = (uint32_t)et - L.found_step;
-        } else {
-        // ---- right walk: two windows from the frame (frame bit of the seed end = 64 + bt + 19)
-        WalkState R{0, 0, 0, 0, false, false, 0};
-        const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
-        const uint32_t rs = bt + SEED_LEN;
-        walk_window_pred(tab, R, ext32(F.dl[2], F.dl[3], F.dl[4], rs), ext32(F.dh[2], F.dh[3], F.dh[4], rs),
-                    ext32(F.cg[2], F.cg[3], F.cg[4], rs), ext32(F.nn[2], F.nn[3], F.nn[4], rs), 0u, maxr, xdrop);
-        if (!R.done)
-            walk_window_pred(tab, R, ext32(F.dl[3], F.dl[4], F.dl[5], rs), ext32(F.dh[3], F.dh[4], F.dh[5], rs),
-                        ext32(F.cg[3], F.cg[4], F.cg[5], rs), ext32(F.nn[3], F.nn[4], F.nn[5], rs), 0u, maxr, xdrop);
-        if (!R.done) {
-            q_med = true;
-        } else if (L.best + R.best >= hspthresh) {
-            q_cd = true;
-            r_cd = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best};
-        }
-        }  // right walk
-        }  // VARIANT != 2
-        }  // gid < nhits
-        // ---- stage the records; a queue is flushed with one atomic when the new records would not fit
-        // (QCAP = 64 = the most one iteration can add), and at the end
-        const bool last = g0 + stride >= nhits;
+        if (active) walk_hit<VARIANT>(tab, T, Q, h, xdrop, hspthresh, transitions, q_med, q_fol, q_cd, r_fk, r_fp, r_cd);
         uint64_t m = __ballot(q_med);
-        if (m || (last && n_med)) {
+        if (m || (final && n_med)) {
             const uint32_t add = (uint32_t)__popcll(m);
-            if (n_med + add > (uint32_t)QCAP) {
+            if (n_med + add > (uint32_t)QCAP || (final && !m)) {
                 __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
@@ -409,7 +547,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
             if (q_med) s_med[wv][n_med + __popcll(m & lt_mask)] = h;
             n_med += add;
-            if (last && n_med) {
+            if (final && n_med) {
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->nmed, (unsigned long long)n_med);
@@ -419,9 +557,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
         }
         m = __ballot(q_fol);
-        if (m || (last && n_fol)) {
+        if (m || (final && n_fol)) {
             const uint32_t add = (uint32_t)__popcll(m);
-            if (n_fol + add > (uint32_t)QCAP) {
+            if (n_fol + add > (uint32_t)QCAP || (final && !m)) {
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
@@ -432,7 +570,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
             if (q_fol) { const uint32_t i = n_fol + __popcll(m & lt_mask); s_fk[wv][i] = r_fk; s_fp[wv][i] = r_fp; }
             n_fol += add;
-            if (last && n_fol) {
+            if (final && n_fol) {
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->nfollow, (unsigned long long)n_fol);
@@ -442,9 +580,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
         }
         m = __ballot(q_cd);
-        if (m || (last && n_cd)) {
+        if (m || (final && n_cd)) {
             const uint32_t add = (uint32_t)__popcll(m);
-            if (n_cd + add > (uint32_t)QCAP) {
+            if (n_cd + add > (uint32_t)QCAP || (final && !m)) {
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
@@ -455,7 +593,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
             if (q_cd) s_cd[wv][n_cd + __popcll(m & lt_mask)] = r_cd;
             n_cd += add;
-            if (last && n_cd) {
+            if (final && n_cd) {
                 __builtin_amdgcn_wave_barrier();
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctr->ncand, (unsigned long long)n_cd);
@@ -465,7 +603,42 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+
+    const uint64_t stride = (uint64_t)gridDim.x * FAST_THREADS;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * FAST_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
+        const uint64_t gid = g0 + lane;
+        uint2 h = make_uint2(0, 0);
+        if (gid < nhits) h = hits[gid];
+        const bool valid = gid < nhits && !(skip_diag0 && h.x == h.y);  // the main diagonal of a self unit belongs to k4_diag0
+        if (!FILTER) {
+            walk_batch(valid, h, false);
+        } else {
+            bool need = false;
+            if (valid)
+                need = VARIANT >= 6 ? hit_needs_walk_full<VARIANT == 6 ? 8 : 16>(T, Q, h, xdrop, hspthresh, transitions)
+                                    : hit_needs_walk<VARIANT == 4 ? 8 : 16>(T, Q, h, xdrop, hspthresh, transitions);
+            const uint64_t m = __ballot(need);
+            if (m) {
+                const uint32_t add = (uint32_t)__popcll(m);
+                if (n_walk + add > (uint32_t)QCAP) {  // walk what is queued (nearly a full wavefront), then queue
+                    __builtin_amdgcn_wave_barrier();
+                    const uint2 hq = s_walk[wv][lane < n_walk ? lane : 0];
+                    walk_batch(lane < n_walk, hq, false);
+                    n_walk = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (need) s_walk[wv][n_walk + __popcll(m & lt_mask)] = h;
+                n_walk += add;
+            }
+        }
     }
+    if (FILTER && n_walk) {
+        __builtin_amdgcn_wave_barrier();
+        const uint2 hq = s_walk[wv][lane < n_walk ? lane : 0];
+        walk_batch(lane < n_walk, hq, false);
+    }
+    walk_batch(false, make_uint2(0, 0), true);  // flush the staged records
 }
 
 // ---- wave-cooperative walk: 64 bases per step ---------------------------------------------
@@ -962,7 +1135,7 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         if (nb > nb_cap) nb = nb_cap;
         // target and query are the same strand of the same scaffold: diagonal 0 is handled by k4_diag0
         const int same_strand = (T.pw == Q.pw && T.len == Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1 : 0;
-        static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 1;
+        static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 5;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
                            p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand, d_nhits)
@@ -974,6 +1147,10 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                                (uint32_t *)W.fprev.p, (uint2 *)W.longq.p, same_strand);
         else if (variant == 2) K4_LAUNCH(2);
         else if (variant == 3) K4_LAUNCH(3);
+        else if (variant == 4) K4_LAUNCH(4);
+        else if (variant == 5) K4_LAUNCH(5);
+        else if (variant == 6) K4_LAUNCH(6);
+        else if (variant == 7) K4_LAUNCH(7);
         else K4_LAUNCH(1);
         if (after_fast && attempt == 0) (*after_fast)();
         // walks still alive after the frame -> generic kernel; beyond LONG_WINDOWS -> wavefront kernel

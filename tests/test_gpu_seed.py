@@ -77,3 +77,23 @@ def test_self_diagonal_present(eng):
     diag = h[h['tpos'] == h['qpos']]
     assert diag.size == 100_000 - 18
     g.close()
+
+
+@pytest.mark.parametrize('big_side', ['target', 'query'])
+def test_tile_with_more_than_65535_entries(eng, big_side):
+    """A satellite array (here 70 kb of poly-A: 70 000 entries under ONE key) on either side: far more
+    entries in a tile than the fill kernel's LDS position cache holds, and beyond 16 bits.  Same hit
+    multiset as the oracle."""
+    from oracle import oracle as O
+    names, seqs = synth_genome(303, 400_000, 2, repeat_frac=0.05, families=2, cons_len=(300, 900))
+    big, small = seqs[0].copy(), seqs[1].copy()
+    big[50_000:120_000] = ord('A')
+    small[1000:1040] = ord('A')      # 22 words that hit the array
+    T, Q = (big, small) if big_side == 'target' else (small, big)
+    g = eng.Genome(['t', 'q'], [T, Q])
+    for strand in (0, 1):
+        got = eng.seed_hits(g, 0, g, 1, strand)
+        exp = O.seed_hits(T.tobytes(), Q.tobytes(), strand)
+        assert got.size == exp.size and got.size > 1_000_000 * (strand == 0), (big_side, strand, got.size, exp.size)
+        assert np.array_equal(_sorted_hits(got), _sorted_hits(exp)), (big_side, strand)
+    g.close()
