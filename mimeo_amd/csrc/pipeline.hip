@@ -4,7 +4,7 @@
 // Pairs are grouped by target scaffold.  A scaffold strand's seed index is built once and
 // kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  Every
 // (target, query, strand) unit goes through K3 (index join) and K4 (gap-free extension) on one of
-// two lanes (host thread + stream); the HSPs of up to MAX_GROUPS units are then chained and
+// three lanes (host thread + stream each); the HSPs of up to MAX_GROUPS units are then chained and
 // gap-extended together (K5/K6, one workgroup per unit in K5, wavefronts per half extension in K6).
 #include <algorithm>
 #include <chrono>
@@ -147,10 +147,14 @@ static uint64_t scan_bytes_kernel(uint64_t nT, uint64_t nQ, uint64_t H) {
 }
 
 // A lane = one host thread + one stream + its own K3/K4 work buffers, taking units off a shared counter.
-// Two lanes keep the GPU busy through the host round trips and the small latency-bound kernels of a
+// Three lanes keep the GPU busy through the host round trips and the small latency-bound kernels of a
 // unit (follower sort, segment resolution, entropy).  The heavy phase of a unit — K3 and the fast K4
 // kernel — is serialised across lanes (HeavyGate): each one starts after the previous one's fast kernel
 // has finished, so the bandwidth-bound seed scan is never sharing the chip with another scan.
+// Why three: a lane's stream is in order, so its next heavy phase cannot start before the tails of its
+// previous unit are through; with the pre-filtered fast kernel (1.8 ms per 10 Mbp x 10 Mbp unit) the tails,
+// squeezed in beside another lane's heavy phase, take about as long as that phase, and with two lanes the
+// chip idled ~0.25 ms per unit waiting for them (rocprofv3 timeline, scripts/timeline_gaps.py).
 struct Lane {
     hipStream_t st = nullptr;
     hipEvent_t heavy_end = nullptr;
@@ -398,7 +402,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     const mimeo_genome *QG = B ? B : A;
     for (uint64_t k = 0; k < npairs; k++)
         if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
-    int nlanes = getenv("MIMEO_LANES") ? atoi(getenv("MIMEO_LANES")) : 2;
+    int nlanes = getenv("MIMEO_LANES") ? atoi(getenv("MIMEO_LANES")) : 3;
     nlanes = std::max(1, std::min(MAX_LANES, nlanes));
     for (int l = 0; l < nlanes; l++) {
         if (!g_lane[l].st) HIP_TRY(hipStreamCreateWithFlags(&g_lane[l].st, hipStreamNonBlocking));
@@ -425,7 +429,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     }
     const bool use_excl = !(getenv("MIMEO_NO_EXCL") && atoi(getenv("MIMEO_NO_EXCL")));
     // units in target-major order (stable in the caller's pair order): neighbouring units share the
-    // target index, and the two lanes work on neighbouring units
+    // target index, and the lanes work on neighbouring units
     std::vector<uint64_t> ord(npairs);
     for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
     std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) { return pair_t[a] < pair_t[b]; });
