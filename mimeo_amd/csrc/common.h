@@ -13,6 +13,9 @@
 //   an extra plane svt = seed validity in the TARGET role (lastz excludes soft-masked target
 //   bases from seeding).  PLANE_PAD zero words lie in front of word 0 and behind the last word
 //   so that window loads never need a bounds check.
+//   A second copy holds the lo / hi planes alone (uint2 per 32 bases, same padding): the K4 pre-filter gathers
+//   ~200 bases around every seed hit and is bound by the bytes it pulls through L2, so it reads this
+//   copy (6.4 + 4 = 10.4 bits per base and strand in all).
 //   The seed index of a strand is CSR: off[2^24 + 1] (u32) and pos[nvalid] (u32, ascending
 //   inside a bucket).  Key = (pext12(lo window) << 12) | pext12(hi window): the low 12 bits are
 //   the transition bits, so the 13 words within one transition of a key differ only in the low
@@ -51,7 +54,9 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 struct StrandView {
     const uint4 *pw;       // interleaved planes {lo, hi, nm, sv}, pointer to word 0
     const uint32_t *svt;   // target-role seed validity plane (word 0), or null: use pw[].w
+    const uint2 *p2;       // the same lo / hi planes alone, 8 bytes per 32 bases (K4 pre-filter: half the bytes to gather)
     uint32_t len;          // bases
+    uint32_t has_n;        // the strand holds at least one non-ACGT base
 };
 
 struct IndexView {
@@ -63,6 +68,8 @@ struct IndexView {
 // host-side owner of one strand's planes
 struct Strand {
     uint4 *base = nullptr;          // nwords + 2*PLANE_PAD interleaved words
+    uint2 *slim = nullptr;          // nwords + 2*PLANE_PAD words of {lo, hi} only
+    bool has_n = false;
     uint32_t *sv_target = nullptr;  // separate sv plane for the target role (soft-mask aware); null = same as sv
     uint32_t nwords = 0;
     uint32_t len = 0;

@@ -8,7 +8,8 @@ namespace mimeo {
 
 // one thread per output word (32 bases): writes the lo/hi/nm components of pw[w]
 __global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, int reverse, uint4 *__restrict__ pw,
-                               uint32_t *__restrict__ lower, uint32_t nwords, uint32_t *__restrict__ any_lower) {
+                               uint2 *__restrict__ slim, uint32_t *__restrict__ lower, uint32_t nwords,
+                               uint32_t *__restrict__ any_lower, uint32_t *__restrict__ any_n) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     uint32_t vlo = 0, vhi = 0, vnm = 0, vlow = 0;
@@ -35,6 +36,8 @@ __global__ void k1_pack_planes(const uint8_t *__restrict__ ascii, uint32_t len, 
         vlow |= low << b;
     }
     pw[w] = make_uint4(vlo, vhi, vnm, 0u);
+    slim[w] = make_uint2(vlo, vhi);
+    if (vnm) atomicOr(any_n, 1u);
     if (lower) {
         lower[w] = vlow;
         if (vlow) atomicOr(any_lower, 1u);
@@ -72,6 +75,8 @@ static int alloc_strand(Strand &s, uint32_t len) {
     size_t per = (size_t)s.nwords + 2 * PLANE_PAD;
     HIP_TRY(hipMalloc((void **)&s.base, per * sizeof(uint4)));
     HIP_TRY(hipMemsetAsync(s.base, 0, per * sizeof(uint4), stream()));
+    HIP_TRY(hipMalloc((void **)&s.slim, per * sizeof(uint2)));
+    HIP_TRY(hipMemsetAsync(s.slim, 0, per * sizeof(uint2), stream()));
     return 0;
 }
 
@@ -79,7 +84,9 @@ StrandView Strand::view(bool as_target) const {
     StrandView v;
     v.pw = base + PLANE_PAD;
     v.svt = (as_target && sv_target) ? sv_target + PLANE_PAD : nullptr;
+    v.p2 = slim + PLANE_PAD;
     v.len = len;
+    v.has_n = has_n ? 1u : 0u;
     return v;
 }
 
@@ -99,15 +106,17 @@ int pack_scaffold(const uint8_t *d_ascii, uint64_t len64, Scaffold &out) {
     d_flag = d_lower + per;
     dim3 blk(256), grd((nwords + 255) / 256);
     uint4 *f = out.fwd.base + PLANE_PAD, *r = out.rc.base + PLANE_PAD;
-    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 0, f, d_lower + PLANE_PAD, nwords, d_flag);
-    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 1, r, (uint32_t *)nullptr, nwords,
-                       (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 0, f, out.fwd.slim + PLANE_PAD, d_lower + PLANE_PAD,
+                       nwords, d_flag, d_flag + 1);
+    hipLaunchKernelGGL(k1_pack_planes, grd, blk, 0, stream(), d_ascii, len, 1, r, out.rc.slim + PLANE_PAD, (uint32_t *)nullptr,
+                       nwords, (uint32_t *)nullptr, d_flag + 1);
     hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), f, (const uint32_t *)nullptr, len, nwords, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k1_seed_valid, grd, blk, 0, stream(), r, (const uint32_t *)nullptr, len, nwords, (uint32_t *)nullptr);
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream()));
+    uint32_t flag[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(flag, d_flag, 8, hipMemcpyDeviceToHost, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
-    out.has_lower = flag != 0;
+    out.has_lower = flag[0] != 0;
+    out.fwd.has_n = out.rc.has_n = flag[1] != 0;
     if (out.has_lower) {
         // the target role excludes soft-masked (lower-case) bases from seeding: separate sv plane
         HIP_TRY(hipMalloc((void **)&out.fwd.sv_target, per * sizeof(uint32_t)));
@@ -125,6 +134,8 @@ void free_scaffold(Scaffold &s) {
     if (s.fwd.base) (void)hipFree(s.fwd.base);
     if (s.fwd.sv_target) (void)hipFree(s.fwd.sv_target);
     if (s.rc.base) (void)hipFree(s.rc.base);
+    if (s.fwd.slim) (void)hipFree(s.fwd.slim);
+    if (s.rc.slim) (void)hipFree(s.rc.slim);
     s.fwd = Strand();
     s.rc = Strand();
 }

@@ -18,6 +18,7 @@
 //   * walks longer than LONG_CAP bases are finished by k4_extend_long, one wavefront per hit,
 //     64 bases per step with wave-level prefix sums.
 //   * k4_entropy applies the entropy adjustment to candidates and the threshold.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -33,7 +34,7 @@ constexpr int EXT_THREADS = 256;
 constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per direction
 
 struct ExtCounters {
-    unsigned long long ncand, nfollow, nlong, nhsp, nmed, nbig;
+    unsigned long long ncand, nfollow, nlong, nhsp, nmed, nbig, nwalked;  // nwalked: hits the pre-filter let through
 };
 
 struct Cand {
@@ -329,6 +330,24 @@ __device__ __forceinline__ void load_frame(const StrandView &T, const StrandView
     }
 }
 
+// the score planes of the same neighbourhood from the two-plane copy (strands without N only): half the bytes
+__device__ __forceinline__ void load_frame_slim(const StrandView &T, const StrandView &Q, const uint2 h, Frame &F) {
+    const uint32_t bt = h.x & 31u, bq = h.y & 31u, sh = (bq - bt) & 31u;
+    const int32_t wt = (int32_t)(h.x >> 5) - 2, wq = (int32_t)(h.y >> 5) - 2 - (bq < bt ? 1 : 0);
+    uint2 tw[6], qw[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) tw[k] = T.p2[wt + k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) qw[k] = Q.p2[wq + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        F.dl[k] = tw[k].x ^ __builtin_amdgcn_alignbit(qw[k + 1].x, qw[k].x, sh);
+        F.dh[k] = tw[k].y ^ __builtin_amdgcn_alignbit(qw[k + 1].y, qw[k].y, sh);
+        F.cg[k] = tw[k].x ^ tw[k].y;
+        F.nn[k] = 0;
+    }
+}
+
 // ---- K4a pre-filter: most seed hits of unrelated sequence are isolated and die at once -------------------
 // A hit can be dropped without walking it when all of this holds inside its frame (64 steps to the left of the
 // seed end, 64 to the right):
@@ -396,11 +415,12 @@ __device__ __forceinline__ FilterMasks filter_left(const Frame &F, uint32_t bt, 
     return m;
 }
 
-template <int STEP>
+template <int STEP, bool SLIM>
 __device__ __forceinline__ bool hit_needs_walk(const StrandView &T, const StrandView &Q, const uint2 h, int xdrop,
                                                int hspthresh, int transitions) {
     Frame F;
-    load_frame(T, Q, h, F);
+    if (SLIM) load_frame_slim(T, Q, h, F);  // neither strand holds an N (the host checked)
+    else load_frame(T, Q, h, F);
     const uint32_t bt = h.x & 31u;
     const FilterMasks l0 = filter_left<0>(F, bt, transitions), l1 = filter_left<1>(F, bt, transitions);
     const uint32_t rs = bt + SEED_LEN;
@@ -417,28 +437,6 @@ __device__ __forceinline__ bool hit_needs_walk(const StrandView &T, const Strand
     return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
 }
 
-// first version of the filter (full masks of the exact path): kept for A/B timing (variants 6 / 7)
-template <int STEP>
-__device__ __forceinline__ bool hit_needs_walk_full(const StrandView &T, const StrandView &Q, const uint2 h, int xdrop,
-                                                    int hspthresh, int transitions) {
-    Frame F;
-    load_frame(T, Q, h, F);
-    const uint32_t bt = h.x & 31u;
-    const WinMasks l0 = left_masks<0>(F, bt, transitions), l1 = left_masks<1>(F, bt, transitions);
-    const uint32_t rs = bt + SEED_LEN;
-    const uint32_t r0dl = ext32(F.dl[2], F.dl[3], F.dl[4], rs), r0dh = ext32(F.dh[2], F.dh[3], F.dh[4], rs),
-                   r0cg = ext32(F.cg[2], F.cg[3], F.cg[4], rs), r0nn = ext32(F.nn[2], F.nn[3], F.nn[4], rs);
-    const uint32_t r1dl = ext32(F.dl[3], F.dl[4], F.dl[5], rs), r1dh = ext32(F.dh[3], F.dh[4], F.dh[5], rs),
-                   r1cg = ext32(F.cg[3], F.cg[4], F.cg[5], rs), r1nn = ext32(F.nn[3], F.nn[4], F.nn[5], rs);
-    if (l0.nn | l1.nn | r0nn | r1nn | l0.H | l1.H) return true;
-    Bound L{0, 0, 0, 0, false}, R{0, 0, 0, 0, false};
-    bound_window<STEP, false>(L, l0.dl, l0.dh, l0.cg, xdrop);
-    bound_window<STEP, false>(L, l1.dl, l1.dh, l1.cg, xdrop);
-    bound_window<STEP, false>(R, r0dl, r0dh, r0cg, xdrop);
-    bound_window<STEP, false>(R, r1dl, r1dh, r1cg, xdrop);
-    return !(L.stop && R.stop && L.ub + R.ub < hspthresh);
-}
-
 // the exact walk of one hit from its frame: classifies it (to the generic kernel / follower / candidate)
 template <int VARIANT>
 __device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const StrandView &T, const StrandView &Q,
@@ -448,6 +446,18 @@ __device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const
     const int32_t d = (int32_t)h.x - (int32_t)h.y;
     const uint32_t bt = h.x & 31u;
     Frame F;
+    if (VARIANT == 8) {  // loads only, with the address pattern of a two-plane (8 bytes per 32 bases) copy: timing experiment
+        const uint32_t bq = h.y & 31u;
+        const int32_t wt = (int32_t)(h.x >> 5) - 2, wq = (int32_t)(h.y >> 5) - 2 - (bq < bt ? 1 : 0);
+        const uint2 *t2 = reinterpret_cast<const uint2 *>(T.pw), *q2 = reinterpret_cast<const uint2 *>(Q.pw);
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const uint2 v = t2[wt + k]; acc ^= v.x ^ v.y; }
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const uint2 v = q2[wq + k]; acc ^= v.x ^ v.y; }
+        if (acc == 0x12345678u) q_med = true;
+        return;
+    }
     if (VARIANT == 3) {  // compute only (timing experiment, wrong results)
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -493,9 +503,9 @@ __device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const
     }
 }
 
-// VARIANT 5 = production: pre-filter with checkpoints every 16 steps; 4 = every 8 steps; 1 = no pre-filter, every hit
-// is walked (the round-1 kernel); 6 / 7 = first version of the filter; 2 = loads only, 3 = compute only (timing
-// experiments, wrong results)
+// VARIANT 9 / 5 = production: pre-filter with checkpoints every 16 steps, reading the two-plane copy (9: neither
+// strand holds an N) or the full planes (5); 4 = every 8 steps; 1 = no pre-filter, every hit is walked; 2 = loads only,
+// 3 = compute only, 8 = loads only from the two-plane copy (timing experiments, wrong results)
 template <int VARIANT>
 __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
                                                               const uint2 *__restrict__ hits, uint64_t nhits_arg,
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                                                               uint32_t *__restrict__ fprev,
                                                               uint2 *__restrict__ medq, int skip_diag0,
                                                               const unsigned long long *__restrict__ nhits_dev) {
-    constexpr bool FILTER = VARIANT >= 4 && VARIANT <= 7;
+    constexpr bool FILTER = VARIANT == 4 || VARIANT == 5 || VARIANT == 9;
     // speculative launch: the count comes from the seed scan on the device, nhits_arg is the buffer capacity
     // (a count beyond it means the scan wrote nothing: no work)
     uint64_t nhits = nhits_arg;
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_med = 0, n_fol = 0, n_cd = 0, n_walk = 0;  // wave-uniform fill levels
+    uint32_t n_med = 0, n_fol = 0, n_cd = 0, n_walk = 0, n_walked = 0;  // wave-uniform fill levels
 
     // walk one hit per lane exactly and stage the records; a queue is flushed with one atomic when the new
     // records would not fit (QCAP = 64 = the most one batch can add); `final` flushes what is left
@@ -616,8 +626,8 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         } else {
             bool need = false;
             if (valid)
-                need = VARIANT >= 6 ? hit_needs_walk_full<VARIANT == 6 ? 8 : 16>(T, Q, h, xdrop, hspthresh, transitions)
-                                    : hit_needs_walk<VARIANT == 4 ? 8 : 16>(T, Q, h, xdrop, hspthresh, transitions);
+                need = VARIANT == 9 ? hit_needs_walk<16, true>(T, Q, h, xdrop, hspthresh, transitions)
+                                    : hit_needs_walk<VARIANT == 4 ? 8 : 16, false>(T, Q, h, xdrop, hspthresh, transitions);
             const uint64_t m = __ballot(need);
             if (m) {
                 const uint32_t add = (uint32_t)__popcll(m);
@@ -625,6 +635,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                     __builtin_amdgcn_wave_barrier();
                     const uint2 hq = s_walk[wv][lane < n_walk ? lane : 0];
                     walk_batch(lane < n_walk, hq, false);
+                    n_walked += n_walk;
                     n_walk = 0;
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -637,7 +648,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         __builtin_amdgcn_wave_barrier();
         const uint2 hq = s_walk[wv][lane < n_walk ? lane : 0];
         walk_batch(lane < n_walk, hq, false);
+        n_walked += n_walk;
     }
+    if (FILTER && n_walked && lane == 0) atomicAdd(&ctr->nwalked, (unsigned long long)n_walked);
     walk_batch(false, make_uint2(0, 0), true);  // flush the staged records
 }
 
@@ -1136,6 +1149,7 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         // target and query are the same strand of the same scaffold: diagonal 0 is handled by k4_diag0
         const int same_strand = (T.pw == Q.pw && T.len == Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1 : 0;
         static int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 5;
+        static const bool force_variant = getenv("MIMEO_K4_VARIANT") != nullptr;  // production: 9 when neither strand holds an N, else 5
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, T, Q, hits, nhits, p->xdrop, \
                            p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand, d_nhits)
@@ -1148,9 +1162,9 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         else if (variant == 2) K4_LAUNCH(2);
         else if (variant == 3) K4_LAUNCH(3);
         else if (variant == 4) K4_LAUNCH(4);
+        else if (variant == 9 || (variant == 5 && !force_variant && !T.has_n && !Q.has_n)) K4_LAUNCH(9);
         else if (variant == 5) K4_LAUNCH(5);
-        else if (variant == 6) K4_LAUNCH(6);
-        else if (variant == 7) K4_LAUNCH(7);
+        else if (variant == 8) K4_LAUNCH(8);
         else K4_LAUNCH(1);
         if (after_fast && attempt == 0) (*after_fast)();
         // walks still alive after the frame -> generic kernel; beyond LONG_WINDOWS -> wavefront kernel
@@ -1203,6 +1217,10 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                            p->hspthresh, p->entropy, W.ctr, (mimeo_hsp *)out_hsps.p);
         HIP_TRY(hipMemcpyAsync(&c, W.ctr, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (getenv("MIMEO_K4_STATS"))
+            fprintf(stderr, "[k4] hits %llu walked %llu (%.2f%%) generic %llu long %llu followers %llu candidates %llu hsps %llu\n",
+                    (unsigned long long)total_h, c.nwalked, total_h ? 100.0 * c.nwalked / total_h : 0.0, c.nmed, c.nlong, c.nfollow,
+                    c.ncand, c.nhsp);
         if (c.ncand <= cand_cap) break;
         if (attempt) { set_error("candidate buffer overflow"); return MIMEO_ERR_LIMIT; }
         cand_cap = c.ncand + 1024;  // rerun with room for every candidate

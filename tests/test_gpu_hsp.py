@@ -137,3 +137,47 @@ def test_parameter_domain_is_enforced(eng):
             eng.align_pairs(g, None, [(0, 1)], eng.default_params(**kw))
     assert eng.ungapped_hsps(g, 0, g, 1, 0, eng.default_params(xdrop=500)).size >= 0
     g.close()
+
+
+def test_prefilter_variants_give_identical_hsps(tmp_path):
+    """The K4 pre-filter (popcount prefix bounds; variants 9 = two-plane copy, 5 = full planes, 4 = finer
+    checkpoints) may only drop hits that the exact walk (variant 1: every hit walked) would drop too:
+    the HSP sets must be byte-identical, on N-free sequence (9 is the default there) and with N runs."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from mimeo_amd import engine\n"
+        "from mimeo_amd.synth import synth_genome\n"
+        "engine.init(0)\n"
+        "names, seqs = synth_genome(91, 1_200_000, 2, repeat_frac=0.15, families=5, cons_len=(200, 3000), max_div=0.2)\n"
+        "seqs = [s.copy() for s in seqs]\n"
+        "if sys.argv[1] == 'n':\n"
+        "    seqs[0][5000:5300] = ord('N'); seqs[1][70000:70010] = ord('N')\n"
+        "g = engine.Genome(names, seqs)\n"
+        "out = []\n"
+        "for t, q in ((0, 1), (0, 0)):\n"
+        "    for strand in (0, 1):\n"
+        "        h = engine.ungapped_hsps(g, t, g, q, strand)\n"
+        "        out.append(h.tobytes())\n"
+        "print(hashlib.sha1(b''.join(out)).hexdigest(), sum(len(o) for o in out) // 32)\n" % root)
+    script = tmp_path / 'v.py'
+    script.write_text(code)
+    for mode in ('clean', 'n'):
+        res = {}
+        for v in ('1', '4', '5', '9', ''):
+            if mode == 'n' and v == '9':
+                continue  # the two-plane copy carries no N plane: the host never selects 9 for such strands
+            env = dict(os.environ)
+            env.pop('MIMEO_K4_VARIANT', None)
+            if v:
+                env['MIMEO_K4_VARIANT'] = v
+            r = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[v or 'default'] = r.stdout.strip().split('\n')[-1]
+        assert len(set(res.values())) == 1, (mode, res)
+        assert int(res['1'].split()[1]) > 100
