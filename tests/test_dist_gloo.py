@@ -28,6 +28,41 @@ def test_shard_pairs_by_target_covers_everything_once():
     assert abs(loads[0] - loads[1]) <= max(cost.values())
 
 
+def test_bench_rows_are_dealt_round_robin_and_cover_the_job():
+    """bench.py row mode: in one step the N ranks hold N different target rows, S/N steps cover every row
+    once, and the dealing of one rank is what N ranks do in N times fewer steps."""
+    sys.path.insert(0, ROOT)
+    import bench
+    S = 100
+    for world in (1, 2, 4, 8):
+        steps = -(-S // world)
+        seen = [bench.row_of(k, world, r, S) for k in range(steps) for r in range(world)]
+        assert sorted(seen[:S]) == list(range(S))
+        for k in range(steps):
+            assert len({bench.row_of(k, world, r, S) for r in range(world)}) == world
+    assert [bench.row_of(k, 1, 0, 6) for k in range(6)] == [bench.row_of(k // 2, 2, k % 2, 6) for k in range(6)]
+
+
+def test_bench_a11_filter_matches_the_printed_identity_rule():
+    """The vectorised A11 filter of bench.py keeps exactly the records formats.tab_block keeps
+    (length1 >= minLen and the PRINTED one-decimal identity >= minIdt, wrappers.py:1043-1052)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from mimeo_amd import _ffi, formats
+    rng = np.random.default_rng(5)
+    a = np.zeros(4000, dtype=_ffi.ALIGNMENT)
+    a['tstart'] = rng.integers(0, 10_000, a.size)
+    a['tend'] = a['tstart'] + rng.integers(1, 400, a.size)
+    a['id_d'] = rng.integers(0, 3000, a.size)
+    a['id_n'] = (a['id_d'] * rng.uniform(0.7, 1.0, a.size)).astype(np.uint32)
+    a['id_n'][:200] = (a['id_d'][:200] * 0.7995).astype(np.uint32)   # near the 79.95 / 80.0 rounding edge
+    a['score'] = np.arange(a.size)
+    got = bench.a11_filter(a, 100, 80)
+    exp = [int(r['score']) for r in a if int(r['tend']) - int(r['tstart']) >= 100
+           and float(formats.identity_pct(int(r['id_n']), int(r['id_d']))) >= 80]
+    assert list(got['score']) == exp and 0 < len(exp) < a.size
+
+
 WORKER = textwrap.dedent('''
     import os, sys
     sys.path.insert(0, %r)
