@@ -39,8 +39,9 @@ struct ExtCounters {
 
 struct Cand {
     uint32_t tstart, qstart, len;
-    int32_t raw;
+    int32_t raw;  // RAW_SATURATED: the score does not fit (a gap-free segment beyond ~21 Mbp); k4_entropy recounts it in 64 bits
 };
+constexpr int32_t RAW_SATURATED = 0x7FFFFFFF;
 
 // is there a seed hit whose 19-window starts at target position p (query p - d)?
 __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandView &Q, int32_t p, int32_t d,
@@ -854,7 +855,8 @@ __device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2
     if (score >= hspthresh && (threadIdx.x & 63) == 0) {
         unsigned long long i = atomicAdd(&ctr->ncand, 1ull);
         if (i < cand_cap)
-            cand[i] = Cand{(uint32_t)et - L.bsteps, (uint32_t)eq - L.bsteps, L.bsteps + R.bsteps, (int32_t)score};
+            cand[i] = Cand{(uint32_t)et - L.bsteps, (uint32_t)eq - L.bsteps, L.bsteps + R.bsteps,
+                           score >= (int64_t)RAW_SATURATED ? RAW_SATURATED : (int32_t)score};  // k4_entropy recounts a saturated score
     }
 }
 
@@ -1037,10 +1039,25 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
     const uint64_t ncand = min((uint64_t)ctr->ncand, cand_cap), nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
     for (uint64_t cid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; cid < ncand; cid += nwaves) {
     Cand c = cand[cid];
-    int64_t adj = c.raw;
+    int64_t raw = c.raw;
+    const int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
+    if (c.raw == RAW_SATURATED) {  // recount the column scores of the segment in 64 bits (wave-uniform, rare)
+        int64_t sum = 0;
+        for (uint32_t o = lane * 32u; o < c.len; o += 64u * 32u) {
+            const int32_t pt = (int32_t)(c.tstart + o);
+            const Win32 tw = win32(T, pt), qw = win32(Q, pt - d);
+            const uint32_t rem = c.len - o, valid = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+            const uint32_t nn = (tw.nm | qw.nm) & valid, dl = (tw.lo ^ qw.lo) & ~nn & valid, dh = (tw.hi ^ qw.hi) & ~nn & valid;
+            const uint32_t cg = tw.lo ^ tw.hi, ok = valid & ~nn;
+            sum += 91ll * __popc(ok) + 9ll * __popc(ok & ~(dl | dh) & cg) - 122ll * __popc(~dl & dh) - 205ll * __popc(dl) -
+                   9ll * __popc(dl & dh) - 2ll * __popc(dl & dh & cg) - 100ll * __popc(nn);
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        raw = sum;
+    }
+    int64_t adj = raw;
     if (entropy) {
         uint32_t cnt[4] = {0, 0, 0, 0};
-        int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
         // four independent windows per iteration: the loads of a long HSP overlap instead of queueing
         for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 4u * 64u * 32u) {
             Win32 tw[4], qw[4];
@@ -1078,12 +1095,12 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(StrandView T, StrandVi
         }
         int64_t q16 = (int64_t)floor(hh * 65536.0 + 0.5);
         q16 = q16 > 65536 ? 65536 : (q16 < 0 ? 0 : q16);
-        adj = ((int64_t)c.raw * q16) >> 16;
+        adj = (raw * q16) >> 16;
     }
     if (adj >= hspthresh && lane == 0) {
         unsigned long long i = atomicAdd(&ctr->nhsp, 1ull);
         mimeo_hsp h;
-        h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = c.raw;
+        h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = raw;
         out[i] = h;
     }
     }

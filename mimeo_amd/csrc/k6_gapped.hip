@@ -46,6 +46,11 @@ struct DpJob {
     uint32_t slot, pad;  // index of this half's HalfResult: 2 * (hsp_begin + anchor rank) + side
 };
 
+// score of a half extension: the identical-suffix shortcut (rows == 0, i > 0) carries 64 bits
+__device__ __forceinline__ int64_t half_score(const HalfResult &r) {
+    return (r.rows == 0 && r.i > 0) ? (int64_t)(((uint64_t)r.maxcols << 32) | (uint32_t)r.score) : (int64_t)r.score;
+}
+
 __device__ __forceinline__ Cell cmax_left(const Cell &l, const Cell &r) { return r.s > l.s ? r : l; }  // ties -> left
 
 // Cross-lane movement with DPP (VALU latency) instead of ds_bpermute (LDS-crossbar latency): the DP
@@ -161,8 +166,8 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         if (!__ballot(!ok)) {
             for (int o = 32; o > 0; o >>= 1) ncg += __shfl_xor(ncg, o);
             uint64_t sc = 100ull * ncg + 91ull * ((uint64_t)n - ncg);
-            best.score = (int32_t)sc; best.i = n; best.j = n; best.nm = n; best.nx = 0;
-            best.overflow = sc >= (1ull << 31) ? 1u : 0u;
+            // rows == 0 marks a shortcut result: its score is 64 bits wide, high word in maxcols (k6_resolve)
+            best.score = (int32_t)(uint32_t)sc; best.maxcols = (uint32_t)(sc >> 32); best.i = n; best.j = n; best.nm = n; best.nx = 0;
             return best;
         }
     }
@@ -382,8 +387,8 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
             for (int w = 0; w < 4; w++) all += ((unsigned long long)sh.last[w] << 32) | sh.first[w];
             __syncthreads();
             unsigned long long sc = 100ull * all + 91ull * ((unsigned long long)n - all);
-            best.score = (int32_t)sc; best.i = n; best.j = n; best.nm = n; best.nx = 0;
-            best.overflow = sc >= (1ull << 31) ? 1u : 0u;
+            // rows == 0 marks a shortcut result: its score is 64 bits wide, high word in maxcols (k6_resolve)
+            best.score = (int32_t)(uint32_t)sc; best.maxcols = (uint32_t)(sc >> 32); best.i = n; best.j = n; best.nm = n; best.nx = 0;
             return best;
         }
     }
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(64) void k6_resolve(Group *__restrict__ groups, con
             mimeo_alignment m;
             m.tid = G.tid; m.qid = G.qid; m.qstrand = G.minus; m.reserved = 0;
             m.tstart = a.x - L.i; m.tend = a.x + R.i; m.qstart = a.y - L.j; m.qend = a.y + R.j;
-            m.score = (int64_t)L.score + R.score;
+            m.score = half_score(L) + half_score(R);
             m.id_n = L.nm + R.nm;
             m.id_d = L.nm + R.nm + L.nx + R.nx;
             aln[b0 + nacc0 + nnew] = m;

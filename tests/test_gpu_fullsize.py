@@ -90,3 +90,26 @@ def test_full_alignment_stage_self_consistency(setup):
     ab = al[(al['tid'] == 0) & (al['qid'] == 1)]
     ba = al[(al['tid'] == 1) & (al['qid'] == 0)]
     assert ab.size > 10 and abs(int(ab.size) - int(ba.size)) <= max(3, ab.size // 10)
+
+
+def test_self_scaffold_beyond_int32_score():
+    """A 24 Mbp scaffold against itself: the trivial diagonal scores 2.3e9 > 2^31 (lastz's own score_t would
+    wrap).  The gap-free stage saturates its 32-bit candidate score and k4_entropy recounts it in 64 bits; the
+    identical-suffix shortcut of K6 carries a 64-bit score.  Checked against numpy: one full-length HSP and
+    one full-length alignment with the exact HOXD70 sum."""
+    from mimeo_amd import engine
+    engine.init(0)
+    rng = np.random.Generator(np.random.PCG64(24))
+    L = 24_000_000
+    code = rng.integers(0, 4, size=L, dtype=np.uint8)
+    seq = np.frombuffer(b'ACGT', np.uint8)[code]
+    exp = int(91 * L + 9 * int(np.count_nonzero((code == 1) | (code == 2))))
+    assert exp > 2 ** 31
+    g = engine.Genome(['big'], [seq])
+    h = engine.ungapped_hsps(g, 0, g, 0, 0)
+    full = h[(h['tstart'] == 0) & (h['qstart'] == 0) & (h['length'] == L)]
+    assert full.size == 1 and int(full['raw_score'][0]) == exp and 0.99 * exp < int(full['score'][0]) <= exp
+    a = engine.align_pair(g, 0, g, 0)
+    triv = a[(a['tstart'] == 0) & (a['tend'] == L) & (a['qstart'] == 0) & (a['qend'] == L) & (a['qstrand'] == 0)]
+    assert triv.size == 1 and int(triv['score'][0]) == exp and int(triv['id_n'][0]) == L == int(triv['id_d'][0])
+    g.close()
