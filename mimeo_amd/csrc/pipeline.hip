@@ -439,21 +439,69 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))
                 units.push_back(Unit{ord[k], pair_t[ord[k]], pair_q[ord[k]], minus});
     std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
+    // Seed indexes cost 64 MiB + 4 bytes per base and strand whatever the scaffold's length, so a genome of thousands
+    // of scaffolds cannot keep them all (2000 scaffolds x 2 strands = 256 GB).  When the indexes a call needs exceed
+    // the budget (60 % of the free device memory; MIMEO_INDEX_BUDGET_MB for tests) the pair matrix is cut into blocks of
+    // Bt targets x Bq queries whose indexes fit, each block with an index cache of its own: S + 2 S^2 / Bt builds
+    // instead of S + 2 S.  Results do not depend on the blocking (they are assembled per pair).
+    std::vector<size_t> block_end;  // unit index where each index block ends
+    {
+        auto idx_bytes = [](uint64_t len) { return ((uint64_t)NBUCKET + 2) * 4 + len * 4; };
+        std::map<uint32_t, uint64_t> tb, qb;  // bytes still to be built per distinct target / query scaffold
+        for (const Unit &u : units) {
+            const Scaffold &ts = A->scaf[u.tid], &qs = QG->scaf[u.qid];
+            StrandView sv;
+            if (!A->kept.count(IndexCache::kept_key(A, IndexCache::key_of(ts, 0, true, &sv)))) tb[u.tid] = idx_bytes(ts.len);
+            if (!QG->kept.count(IndexCache::kept_key(QG, IndexCache::key_of(qs, (int)u.minus, false, &sv))))
+                qb[u.qid] = std::max<uint64_t>(qb[u.qid], idx_bytes(qs.len) * ((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH ? 2 : 1));
+        }
+        uint64_t need = 0, tmax = 1, qmax = 1;
+        for (auto &kv : tb) { need += kv.second; tmax = std::max(tmax, kv.second); }
+        for (auto &kv : qb) { need += kv.second; qmax = std::max(qmax, kv.second); }
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = (uint64_t)(0.6 * (double)free_b);
+        if (getenv("MIMEO_INDEX_BUDGET_MB")) budget = (uint64_t)atol(getenv("MIMEO_INDEX_BUDGET_MB")) << 20;
+        if (need > budget && !units.empty()) {
+            const uint64_t Bt = std::max<uint64_t>(1, budget / 2 / tmax), Bq = std::max<uint64_t>(1, budget / 2 / qmax);
+            std::map<uint32_t, uint64_t> trank, qrank;
+            for (const Unit &u : units) { trank[u.tid]; qrank[u.qid]; }
+            uint64_t r = 0;
+            for (auto &kv : trank) kv.second = r++ / Bt;
+            r = 0;
+            for (auto &kv : qrank) kv.second = r++ / Bq;
+            std::stable_sort(units.begin(), units.end(), [&](const Unit &a, const Unit &b) {
+                const uint64_t ta = trank[a.tid], tbk = trank[b.tid], qa = qrank[a.qid], qbk = qrank[b.qid];
+                if (ta != tbk) return ta < tbk;
+                if (qa != qbk) return qa < qbk;
+                return a.tid < b.tid;  // target-major inside a block; the two strands of a pair stay adjacent (stable)
+            });
+            for (size_t i = 1; i <= units.size(); i++)
+                if (i == units.size() || trank[units[i].tid] != trank[units[i - 1].tid] || qrank[units[i].qid] != qrank[units[i - 1].qid])
+                    block_end.push_back(i);
+        } else {
+            block_end.push_back(units.size());
+        }
+    }
+    float ms_chain = 0, ms_gapped = 0, ms_index = 0;
+    int rc = 0;
+    const size_t MAX_GROUPS = 8192;  // units per K5/K6 batch
+    HIP_TRY(hipStreamSynchronize(stream()));
+    size_t blk_begin = 0;
+    for (size_t blk = 0; blk < block_end.size() && !rc; blk_begin = block_end[blk], blk++) {
+    const size_t blk_end = block_end[blk];
     IndexCache cache;
     {
         std::set<IndexCache::Key> seen;
-        for (const Unit &u : units) {
+        for (size_t i = blk_begin; i < blk_end; i++) {
+            const Unit &u = units[i];
             cache.want(A, A->scaf[u.tid], 0, true, seen);
             cache.want(QG, QG->scaf[u.qid], (int)u.minus, false, seen);
         }
     }
-    float ms_chain = 0, ms_gapped = 0;
-    int rc = 0;
-    const size_t MAX_GROUPS = 8192;  // units per K5/K6 batch
-    HIP_TRY(hipStreamSynchronize(stream()));
     cache.start(index_stream);
-    for (size_t b0 = 0; b0 < units.size() && !rc; b0 += MAX_GROUPS) {
-        size_t b1 = std::min(units.size(), b0 + MAX_GROUPS);
+    for (size_t b0 = blk_begin; b0 < blk_end && !rc; b0 += MAX_GROUPS) {
+        size_t b1 = std::min(blk_end, b0 + MAX_GROUPS);
         Batch batch;
         batch.groups.resize(b1 - b0);
         batch.group_pair.resize(b1 - b0);
@@ -476,6 +524,9 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         if (r.rc) { rc = r.rc; set_error(r.err); }
     }
     cache.clear();
+    ms_index += cache.ms;
+    g_stats.index_blocks++;
+    }  // index blocks
     if (rc) return rc;
     uint64_t total = 0;
     for (auto &v : per_pair) total += v.size();
@@ -486,7 +537,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     *out = res;
     *nout = total;
     g_stats.alignments = total;
-    g_stats.ms_index = cache.ms;
+    g_stats.ms_index = ms_index;
     for (int l = 0; l < nlanes; l++) {
         g_stats.ms_scan += g_lane[l].tm.ms_count + g_lane[l].tm.ms_fill;
         g_stats.ms_scan_fill += g_lane[l].tm.ms_fill;

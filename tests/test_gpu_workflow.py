@@ -282,3 +282,25 @@ def test_kept_seed_indexes_are_reused_and_change_nothing(eng):
     with pytest.raises(RuntimeError):
         A.drop_indexes([99])
     A.close(); B.close()
+
+
+def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
+    """A genome of many scaffolds cannot keep every seed index (64 MiB + 4 B/base per strand) on the device: the
+    pair matrix is then cut into blocks whose indexes fit, rebuilt block by block.  Same records as one block."""
+    from mimeo_amd import workflow
+    names, seqs = synth_genome(123, 600_000, 6, repeat_frac=0.25, families=3, cons_len=(300, 1500), max_div=0.1)
+    A = eng.Genome(names, seqs)
+    pairs = workflow.all_pairs(6)
+    whole = eng.align_pairs(A, None, pairs)
+    assert eng.stats()['index_blocks'] == 1 and whole.size > 50
+    monkeypatch.setenv('MIMEO_INDEX_BUDGET_MB', '300')   # room for about two target and one query scaffold (both strands)
+    blocked = eng.align_pairs(A, None, pairs)
+    st = eng.stats()
+    assert st['index_blocks'] >= 9, st['index_blocks']
+    assert blocked.tobytes() == whole.tobytes()
+    sub = [(5, 0), (0, 5), (2, 2), (3, 1)]                # an arbitrary pair list, not a full matrix
+    monkeypatch.delenv('MIMEO_INDEX_BUDGET_MB')
+    ref = eng.align_pairs(A, None, sub)
+    monkeypatch.setenv('MIMEO_INDEX_BUDGET_MB', '300')
+    assert eng.align_pairs(A, None, sub).tobytes() == ref.tobytes()
+    A.close()
