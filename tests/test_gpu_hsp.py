@@ -181,3 +181,39 @@ def test_prefilter_variants_give_identical_hsps(tmp_path):
             res[v or 'default'] = r.stdout.strip().split('\n')[-1]
         assert len(set(res.values())) == 1, (mode, res)
         assert int(res['1'].split()[1]) > 100
+
+
+def test_tiny_scaffolds_and_hits_at_the_ends(eng):
+    """Scaffolds of 19..300 bases carrying copies of one another flush with their ends: every frame of the
+    pre-filter and of the exact walk hangs over a sequence end (zero padding), on both strands."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    names, seqs = [], []
+    core = rng.integers(0, 4, size=400, dtype=np.uint8)
+    for k in range(24):
+        n = int(rng.choice([19, 20, 37, 64, 83, 100, 147, 200, 300]))
+        s = rng.integers(0, 4, size=n, dtype=np.uint8)
+        m = int(rng.integers(19, n + 1))
+        off = int(rng.integers(0, 400 - m + 1))
+        piece = core[off:off + m].copy()
+        if rng.random() < 0.5:
+            piece = (3 - piece)[::-1]
+        where = int(rng.choice([0, n - m]))          # flush with the start or with the end
+        s[where:where + m] = piece
+        for _ in range(int(rng.integers(0, 3))):     # a few substitutions inside
+            s[int(rng.integers(0, n))] = int(rng.integers(0, 4))
+        names.append('t%d' % k)
+        seqs.append(np.frombuffer(b'ACGT', np.uint8)[s])
+    g = eng.Genome(names, seqs)
+    cols = ['tstart', 'qstart', 'length', 'score', 'raw_score']
+    nh = 0
+    for kw in ({'hspthresh': 1000}, {'hspthresh': 1800, 'xdrop': 500}):
+        for t in range(0, 24, 6):
+            for q in range(24):
+                for strand in (0, 1):
+                    a = eng.ungapped_hsps(g, t, g, q, strand, eng.default_params(**kw))
+                    b = O.ungapped_hsps(seqs[t].tobytes(), seqs[q].tobytes(), strand, O.default_params(**kw))
+                    assert np.array_equal(np.sort(a[cols], order=cols), np.sort(b[cols], order=cols)), (kw, t, q, strand)
+                    nh += b.size
+    assert nh > 40
+    g.close()
