@@ -6,7 +6,9 @@
 //   * chain DP  best[j] = score[j] + max(0, max{best[i] : i ends at or before the start of j in both
 //     sequences}), evaluated forward in tiles of 64: one wavefront finalises a tile (lane = HSP,
 //     64 shuffle steps), then the whole workgroup relaxes every later HSP against the tile's 64
-//     final values from LDS.  Tiles and the members of a tile are visited in ascending order and
+//     final values from LDS — by one binary search in the tile's members ordered by query end (with
+//     their running best) when the HSP starts behind the whole tile in the target, member by member
+//     otherwise.  Tiles and the members of a tile are visited in ascending order and
 //     only a strict improvement replaces a predecessor, so ties go to the earliest predecessor
 //     and the earliest chain end;
 //   * flag the chain and order the chained HSPs by (score desc, tstart, qstart, length) — the
@@ -73,6 +75,10 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
     __shared__ uint32_t s_m;
     __shared__ uint32_t s_te[CH_TILE], s_qe[CH_TILE];
     __shared__ long long s_b[CH_TILE];
+    // the same tile ordered by query end, with the running best (and its tile member) over that order: an HSP that
+    // starts behind every member of the tile in the target finds its best predecessor by one binary search
+    __shared__ uint32_t s_sqe[CH_TILE], s_pmi[CH_TILE], s_maxte;
+    __shared__ long long s_pmb[CH_TILE];
     if (n == 0) { if (tid == 0) G.nchain = 0; return; }
     // 1. hs[b0 .. b0+n) arrives sorted by (tstart, qstart, length) (device-wide radix sorts, chain_device)
     if (do_chain) {
@@ -95,12 +101,36 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
                     const uint32_t tej = (uint32_t)__shfl((int)te, (int)jj), qej = (uint32_t)__shfl((int)qe, (int)jj);
                     if (live && tid > jj && tej <= hj.tstart && qej <= hj.qstart && bj > cj) { cj = bj; pj = (int)(t0 + jj); }
                 }
+                const long long bfin = cj + hj.score;
                 if (live) {
-                    const long long bj = cj + hj.score;
-                    best[b0 + j] = bj;
+                    best[b0 + j] = bfin;
                     pred[b0 + j] = pj;
-                    s_te[tid] = te; s_qe[tid] = qe; s_b[tid] = bj;
+                    s_te[tid] = te; s_qe[tid] = qe; s_b[tid] = bfin;
                 }
+                // bitonic sort of the 64 members by (query end, member) with shuffles; dead lanes sort to the end
+                uint32_t kq = live ? qe : 0xFFFFFFFFu, ki = tid;
+                long long kb = live ? bfin : INT64_MIN;
+                for (uint32_t k = 2; k <= 64; k <<= 1)
+                    for (uint32_t jx = k >> 1; jx > 0; jx >>= 1) {
+                        const uint32_t oq = (uint32_t)__shfl_xor((int)kq, (int)jx), oi = (uint32_t)__shfl_xor((int)ki, (int)jx);
+                        const long long ob = __shfl_xor(kb, (int)jx);
+                        const bool up = (tid & k) == 0, lower = (tid & jx) == 0;
+                        const bool mine_less = kq < oq || (kq == oq && ki < oi);
+                        const bool keep = (lower == up) ? mine_less : !mine_less;   // keep the smaller in the lower lane of an ascending pair
+                        if (!keep) { kq = oq; ki = oi; kb = ob; }
+                    }
+                // inclusive running maximum of the final values in that order; ties to the smaller member
+                long long pb = kb;
+                uint32_t pi = ki;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const long long ub = __shfl_up(pb, o);
+                    const uint32_t ui = (uint32_t)__shfl_up((int)pi, o);
+                    if (tid >= (uint32_t)o && (ub > pb || (ub == pb && ui < pi))) { pb = ub; pi = ui; }
+                }
+                s_sqe[tid] = kq; s_pmb[tid] = pb; s_pmi[tid] = pi;
+                uint32_t mte = live ? te : 0u;
+                for (int o = 32; o > 0; o >>= 1) mte = max(mte, (uint32_t)__shfl_xor((int)mte, o));
+                if (tid == 0) s_maxte = mte;
             }
             __syncthreads();
             // b. everybody relaxes the HSPs behind the tile against its final values
@@ -110,8 +140,19 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
                 const uint32_t ts = hk.tstart, qs = hk.qstart;
                 long long c = cand[b0 + k];
                 int pk = -2;
-                for (uint32_t ii = 0; ii < cnt; ii++)
-                    if (s_te[ii] <= ts && s_qe[ii] <= qs && s_b[ii] > c) { c = s_b[ii]; pk = (int)(t0 + ii); }
+                if (s_maxte <= ts) {
+                    // every member ends in front of this HSP in the target: the best one among those that also end in
+                    // front of it in the query = running maximum at the last sorted member with query end <= qs
+                    uint32_t lo = 0, hi = CH_TILE;  // number of sorted members with query end <= qs
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_sqe[mid] <= qs) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo && s_pmb[lo - 1] > c) { c = s_pmb[lo - 1]; pk = (int)(t0 + s_pmi[lo - 1]); }
+                } else {
+                    for (uint32_t ii = 0; ii < cnt; ii++)
+                        if (s_te[ii] <= ts && s_qe[ii] <= qs && s_b[ii] > c) { c = s_b[ii]; pk = (int)(t0 + ii); }
+                }
                 if (pk != -2) { cand[b0 + k] = c; pred[b0 + k] = pk; }
             }
             __syncthreads();
