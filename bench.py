@@ -19,7 +19,7 @@ per second = (1 Gbp genome) / (time the whole job takes at that rate).
 Job mode (workloads c2, small, c3, c5, ...: the other BASELINE configs, development aids): a step is the
 whole job, pairs sharded over ranks, "scaling" "strong" (the round-1 bench line for C2 is kept in profiles/).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4small|c2|small|c3|c5|c3small|c5small] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4small|c4job|c2|small|c3|c5|c3small|c5small] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -37,6 +37,7 @@ WORKLOADS = {
     'c4': ('self', 1000, None, 1_000_000_000, 100, 80, 3, 'row'),
     'c4small': ('self', 1000, None, 6_000_000, 6, 80, 3, 'row'),   # the row-mode code path at test size
     # the other BASELINE configs, runnable for development (not bench lines; SURVEY §8 sizes)
+    'c4job': ('self', 1000, None, 1_000_000_000, 100, 80, 3, 'job'),   # the whole 1 Gbp job in ONE call (a minute per step)
     'c2': ('self', 50, None, 50_000_000, 10, 80, 3, 'job'),
     'small': ('self', 50, None, 4_000_000, 4, 80, 3, 'job'),
     'c3': ('x', 201, 202, 200_000_000, 20, 80, 5, 'job'),
