@@ -127,7 +127,8 @@ typedef struct mimeo_stats {
     uint64_t scan_launches;       /* number of seed-scan fill launches timed in ms_scan_fill */
     double ms_scan_fill;          /* HIP-event time of the fill kernel alone (the roofline kernel) */
     uint64_t index_blocks;        /* blocks the pair matrix was cut into so that the seed indexes fit in memory (1 = none) */
-    uint64_t reserved[5];
+    uint64_t lanes;               /* lanes (host thread + stream + work buffers) the call used: fewer for large scaffolds */
+    uint64_t reserved[4];
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */

@@ -404,6 +404,20 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
     int nlanes = getenv("MIMEO_LANES") ? atoi(getenv("MIMEO_LANES")) : 3;
     nlanes = std::max(1, std::min(MAX_LANES, nlanes));
+    {
+        // every lane owns hit, follower and queue buffers for its unit (36 bytes per expected seed hit, with the 1.5x
+        // margin of the speculative launch): large scaffolds get fewer lanes so that the buffers stay within ~35 % of
+        // the device memory (three lanes up to ~17 Mbp x 17 Mbp, one lane from ~30 Mbp x 30 Mbp)
+        double worst = 0;
+        for (uint64_t k = 0; k < npairs; k++)
+            worst = std::max(worst, (double)A->scaf[pair_t[k]].len * (double)QG->scaf[pair_q[k]].len);
+        const double per_lane = (13.0 * worst / 16777216.0 * 1.5 + 4194304.0) * 36.0;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        double budget = 0.35 * (double)total_b;
+        if (getenv("MIMEO_LANE_BUDGET_MB")) budget = (double)atol(getenv("MIMEO_LANE_BUDGET_MB")) * 1048576.0;
+        nlanes = std::max(1, std::min(nlanes, (int)(budget / per_lane)));
+    }
     for (int l = 0; l < nlanes; l++) {
         if (!g_lane[l].st) HIP_TRY(hipStreamCreateWithFlags(&g_lane[l].st, hipStreamNonBlocking));
         if (!g_lane[l].heavy_end) HIP_TRY(hipEventCreateWithFlags(&g_lane[l].heavy_end, hipEventDisableTiming));
@@ -526,6 +540,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     cache.clear();
     ms_index += cache.ms;
     g_stats.index_blocks++;
+    g_stats.lanes = (uint64_t)nlanes;
     }  // index blocks
     if (rc) return rc;
     uint64_t total = 0;

@@ -298,6 +298,10 @@ def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
     st = eng.stats()
     assert st['index_blocks'] >= 9, st['index_blocks']
     assert blocked.tobytes() == whole.tobytes()
+    assert st['lanes'] == 3
+    monkeypatch.setenv('MIMEO_LANE_BUDGET_MB', '200')      # the lanes' buffers of large scaffolds would not fit: one lane
+    assert eng.align_pairs(A, None, pairs).tobytes() == whole.tobytes() and eng.stats()['lanes'] == 1
+    monkeypatch.delenv('MIMEO_LANE_BUDGET_MB')
     sub = [(5, 0), (0, 5), (2, 2), (3, 1)]                # an arbitrary pair list, not a full matrix
     monkeypatch.delenv('MIMEO_INDEX_BUDGET_MB')
     ref = eng.align_pairs(A, None, sub)
