@@ -128,7 +128,8 @@ typedef struct mimeo_stats {
     double ms_scan_fill;          /* HIP-event time of the fill kernel alone (the roofline kernel) */
     uint64_t index_blocks;        /* blocks the pair matrix was cut into so that the seed indexes fit in memory (1 = none) */
     uint64_t lanes;               /* lanes (host thread + stream + work buffers) the call used: fewer for large scaffolds */
-    uint64_t reserved[4];
+    uint64_t chunked_units;       /* units whose query was joined chunk by chunk (more than MIMEO_CHUNK_HITS expected seed hits) */
+    uint64_t reserved[3];
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */

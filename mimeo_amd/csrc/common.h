@@ -121,7 +121,8 @@ void free_scaffold(Scaffold &s);
 int load_fasta_impl(const char *const *paths, uint32_t npaths, const char *split_dir, mimeo_genome **out);
 
 // K2: seed index of one strand (k2_index.hip)
-int build_index(const StrandView &s, SeedIndex &out, float *ms);
+// [p0, p1): index only the seed words that start in that range (chunks of a very large query; default = all)
+int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0 = 0, uint32_t p1 = 0xFFFFFFFFu);
 
 // K3: index join (k3_join.hip).  Produces all seed hits of (T, Q) into a device buffer the
 // caller owns (grown on demand).
@@ -182,10 +183,19 @@ struct ExtWork {  // per-lane work state of K4
 // launched: the point where a concurrent lane may start its own heavy phase.
 // d_nhits != null: speculative — `nhits` is the capacity of `hits`, the real count is read by the kernels
 // from *d_nhits and returned in *nhits_out; MIMEO_RETRY_EXACT if it exceeded the capacity.
+// `chunk` (optional): the unit's hits arrive in several calls (a very large unit whose query is joined chunk by chunk,
+// pipeline.hip).  Heads are decided from the sequences alone and are finished per call; followers and candidates
+// accumulate in W and are resolved in the call flagged `last` — a follower chain may cross a chunk border.
+struct ExtChunk {
+    int first, last;
+    uint64_t cand_cap;        // candidate capacity of the whole unit (no rerun in chunked mode)
+    uint64_t nfollow_before;  // followers gathered by the earlier chunks (in)
+    uint64_t nfollow_after;   // ... including this one (out)
+};
 int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
                          const std::function<void()> *after_fast = nullptr, const unsigned long long *d_nhits = nullptr,
-                         uint64_t *nhits_out = nullptr);
+                         uint64_t *nhits_out = nullptr, ExtChunk *chunk = nullptr);
 
 // K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
 constexpr int MAX_BATCH = 32;

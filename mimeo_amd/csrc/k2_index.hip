@@ -8,6 +8,7 @@
 // The (key,pos) ordering uses rocPRIM's device radix sort: this is plumbing executed 2*S times
 // per job against S^2*2 seed scans, not a hot kernel.
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -25,7 +26,7 @@ __device__ __forceinline__ uint32_t pext12(uint32_t x) {
 
 // one thread per 32 start positions: keys (1<<24 for "no seed here") + histogram
 __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict__ keys,
-                             uint32_t *__restrict__ posv, uint32_t *__restrict__ hist) {
+                             uint32_t *__restrict__ posv, uint32_t *__restrict__ hist, uint32_t p0, uint32_t p1) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     const uint4 a = s.pw[w], c = s.pw[w + 1];
@@ -38,7 +39,7 @@ __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict
         uint32_t p = base + b;
         if (p >= s.len) break;
         uint32_t key = NBUCKET;
-        if ((sv >> b) & 1u) {
+        if (((sv >> b) & 1u) && p >= p0 && p < p1) {  // [p0, p1): the whole strand, or one chunk of a very large query
             uint32_t wl = (uint32_t)(lo >> b) & 0x7FFFFu, wh = (uint32_t)(hi >> b) & 0x7FFFFu;
             key = (pext12(wl) << 12) | pext12(wh);
             atomicAdd(&hist[key], 1u);
@@ -78,7 +79,10 @@ void SeedIndex::release() {
     pos_bytes = 0;
 }
 
-int build_index(const StrandView &s, SeedIndex &out, float *ms) {
+int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0, uint32_t p1) {
+    // one build at a time: the workspace and the event pair are shared (index builder thread, lanes joining a chunked unit)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     out.release();
     uint32_t len = s.len;
     uint32_t nwords = (len + 31) / 32;
@@ -98,7 +102,7 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms) {
     if ((rc = pool_alloc((void **)&out.pos, out.pos_bytes))) return rc;
     if (nwords)
         hipLaunchKernelGGL(k2_seed_keys, dim3((nwords + 255) / 256), dim3(256), 0, stream(), s, nwords, keys_in,
-                           pos_in, hist);
+                           pos_in, hist, p0, p1);
     // off = exclusive scan of hist over NBUCKET+1 entries (entry NBUCKET = total)
     size_t tmp_bytes = 0, tmp2 = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, hist, out.off, 0u, (size_t)NBUCKET + 1, rocprim::plus<uint32_t>(),

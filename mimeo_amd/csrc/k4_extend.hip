@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <utility>
 
 #include <rocprim/rocprim.hpp>
 
@@ -1147,9 +1148,11 @@ void ExtWork::release() {
 
 int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
                          const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
-                         const std::function<void()> *after_fast, const unsigned long long *d_nhits, uint64_t *nhits_out) {
+                         const std::function<void()> *after_fast, const unsigned long long *d_nhits, uint64_t *nhits_out,
+                         ExtChunk *chunk) {
     hipStream_t st = stream();
     *nhsp = 0;
+    const bool first = !chunk || chunk->first, last = !chunk || chunk->last;
     if (T.len >= 0x7FFFFF00u || Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
     if (!W.ctr) HIP_TRY(hipMalloc((void **)&W.ctr, sizeof(ExtCounters)));
     int tab_rc = 0;
@@ -1163,8 +1166,8 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         }
     });
     if (tab_rc || !g_group_tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
-    HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
-    if (!nhits && !d_nhits) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
+    if (first) HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+    if (!nhits && !d_nhits && !chunk) { return out_hsps.reserve(sizeof(mimeo_hsp)); }
     unsigned long long total_h = nhits;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -1174,18 +1177,38 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
     // exact size in the rare overflow case.  Kernels that consume a queue read its length from device
     // memory and run on fixed grids, so one host synchronisation (follower count, needed to size the
     // sort) and a final one are all a unit costs.
-    uint64_t cand_cap = nhits / 32 + 65536;
+    uint64_t cand_cap = chunk ? chunk->cand_cap : nhits / 32 + 65536;
     int rc;
     ExtCounters c;
     for (int attempt = 0;; attempt++) {
-        if ((rc = W.cand.reserve(cand_cap * sizeof(Cand)))) return rc;
-        if ((rc = out_hsps.reserve(cand_cap * sizeof(mimeo_hsp)))) return rc;
-        if ((rc = W.fkey.reserve(nhits * 8))) return rc;
-        if ((rc = W.fprev.reserve(nhits * 4))) return rc;
+        if (first) {
+            if ((rc = W.cand.reserve(cand_cap * sizeof(Cand)))) return rc;
+            if ((rc = out_hsps.reserve(cand_cap * sizeof(mimeo_hsp)))) return rc;
+        }
+        if (chunk && !first) {
+            // the followers of the earlier chunks of this unit stay in front: grow with their content kept
+            const uint64_t keep = chunk->nfollow_before, want = keep + nhits;
+            for (auto bw : {std::make_pair(&W.fkey, (size_t)8), std::make_pair(&W.fprev, (size_t)4)}) {
+                if (bw.first->cap >= want * bw.second) continue;
+                DeviceBuf bigger;
+                if ((rc = bigger.reserve(want * bw.second))) return rc;
+                if (keep) HIP_TRY(hipMemcpyAsync(bigger.p, bw.first->p, keep * bw.second, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                bw.first->release();
+                *bw.first = bigger;
+            }
+        } else {
+            if ((rc = W.fkey.reserve(nhits * 8))) return rc;
+            if ((rc = W.fprev.reserve(nhits * 4))) return rc;
+        }
         if ((rc = W.longq.reserve(nhits * 8))) return rc;
         if ((rc = W.medq.reserve(nhits * 8))) return rc;
         if ((rc = W.nsel.reserve(16))) return rc;
-        HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+        if (first) HIP_TRY(hipMemsetAsync(W.ctr, 0, sizeof(ExtCounters), st));
+        else {  // the per-chunk queues restart; candidates and followers go on
+            HIP_TRY(hipMemsetAsync(&W.ctr->nlong, 0, sizeof(unsigned long long), st));
+            HIP_TRY(hipMemsetAsync(&W.ctr->nmed, 0, sizeof(unsigned long long), st));
+        }
         HIP_TRY(hipMemsetAsync(W.nsel.p, 0, 16, st));
         uint64_t nb = (nhits + FAST_THREADS - 1) / FAST_THREADS;
         // grid-stride over one resident set of workgroups (4 per CU): each loads the 16 KiB group table once.  Four
@@ -1200,7 +1223,9 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                            p->hspthresh, p->transitions, (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, \
                            (uint64_t *)W.fkey.p, (uint32_t *)W.fprev.p, (uint2 *)W.medq.p, same_strand, d_nhits)
         if (variant == 0 && d_nhits) return MIMEO_RETRY_EXACT;  // the development variant has no capacity guard
-        if (variant == 0)
+        if (nb == 0) {
+            // an empty chunk of a chunked unit: nothing to launch
+        } else if (variant == 0)
             hipLaunchKernelGGL(k4_extend_generic, dim3((uint32_t)(nb * 2)), dim3(EXT_THREADS), 0, st, T, Q, hits, nhits,
                                (const unsigned long long *)nullptr, p->xdrop, p->hspthresh, p->transitions,
                                (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
@@ -1218,7 +1243,7 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                            (uint64_t)0, (const unsigned long long *)&W.ctr->nmed, p->xdrop, p->hspthresh, p->transitions,
                            (const uint32_t *)g_group_tab, W.ctr, (Cand *)W.cand.p, cand_cap, (uint64_t *)W.fkey.p,
                            (uint32_t *)W.fprev.p, (uint2 *)W.longq.p, 0);
-        if (same_strand)
+        if (same_strand && first)
             hipLaunchKernelGGL(k4_diag0, dim3(1), dim3(64), 0, st, T, Q, p->xdrop, p->hspthresh, p->transitions, W.ctr,
                                (Cand *)W.cand.p, cand_cap);
         hipLaunchKernelGGL(k4_extend_long, dim3(64), dim3(EXT_THREADS), 0, st, T, Q, (const uint2 *)W.longq.p, p->xdrop,
@@ -1229,6 +1254,15 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
         HIP_TRY(hipStreamSynchronize(st));
         if (nhits_out) *nhits_out = total_h;
         if (d_nhits && total_h > nhits) return MIMEO_RETRY_EXACT;  // nothing was written; the caller repeats the unit
+        if (chunk) {
+            chunk->nfollow_after = c.nfollow;
+            if (c.ncand > cand_cap) { set_error("candidate buffer overflow in a chunked unit"); return MIMEO_ERR_LIMIT; }
+            if (!last) {  // more chunks of this unit follow: followers and candidates wait for the last one
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                return 0;
+            }
+        }
         if (c.nfollow) {
             uint64_t nf = c.nfollow;
             if ((rc = W.fkey2.reserve(nf * 8))) return rc;
@@ -1268,7 +1302,7 @@ int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, c
                     (unsigned long long)total_h, c.nwalked, total_h ? 100.0 * c.nwalked / total_h : 0.0, c.nmed, c.nlong, c.nfollow,
                     c.ncand, c.nhsp);
         if (c.ncand <= cand_cap) break;
-        if (attempt) { set_error("candidate buffer overflow"); return MIMEO_ERR_LIMIT; }
+        if (attempt || chunk) { set_error("candidate buffer overflow"); return MIMEO_ERR_LIMIT; }
         cand_cap = c.ncand + 1024;  // rerun with room for every candidate
     }
     HIP_TRY(hipEventRecord(e1, st));

@@ -8,6 +8,7 @@
 // gap-extended together (K5/K6, one workgroup per unit in K5, wavefronts per half extension in K6).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -312,6 +313,37 @@ static void lane_main(Lane *ln, Shared *sh) {
         // scan and the fast K4 kernel, so the lane hands the heavy phase on at once.  A unit that does not
         // fit (the kernels then do nothing) is repeated with the exact count.
         const double expect = 13.0 * (double)ti.n * (double)qi.n / 16777216.0;
+        // A unit too large for one pass (2^32 hits are the limit of the hit indices, and every hit costs 36 bytes
+        // of work buffers): the query is joined chunk by chunk — an index over a range of query positions per chunk,
+        // hit coordinates stay global — with the followers and candidates of all chunks resolved together at the end
+        // (ExtChunk, common.h).  The unit keeps the heavy-phase gate for its whole duration.
+        const double chunk_hits = getenv("MIMEO_CHUNK_HITS") ? atof(getenv("MIMEO_CHUNK_HITS")) : 1.5e9;
+        if (expect > chunk_hits) {
+            const uint32_t nchunks = (uint32_t)std::min(4096.0, std::ceil(expect / (0.67 * chunk_hits)));
+            sh->gate.acquire(st);
+            ExtChunk ch{1, 0, (uint64_t)(expect / 32.0) + (1u << 20), 0, 0};
+            for (uint32_t c = 0; c < nchunks && !rc; c++) {
+                const uint32_t p0 = (uint32_t)((uint64_t)qv.len * c / nchunks), p1 = (uint32_t)((uint64_t)qv.len * (c + 1) / nchunks);
+                SeedIndex qc;
+                float ms_idx = 0;
+                uint64_t n = 0;
+                if ((rc = build_index(qv, qc, &ms_idx, p0, p1))) break;
+                rc = join_hits(ln->jc, ti, qc.view(), p->transitions, ln->hits, &n, &ln->tm, sh->excl, 0);
+                ch.first = c == 0;
+                ch.last = c + 1 == nchunks;
+                ch.nfollow_before = ch.nfollow_after;
+                if (!rc)
+                    rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, n, p, ln->unit_hsps, &nh, &ln->ms_ext, nullptr,
+                                              nullptr, nullptr, &ch);
+                nhits += n;
+                qc.release();
+            }
+            (void)sh->gate.release(st, ln->heavy_end, nullptr);
+            sh->cache->token();
+            if (rc) { fail(rc); break; }
+            std::lock_guard<std::mutex> lk(sh->mu);
+            g_stats.chunked_units++;
+        } else {
         uint64_t spec_cap = sh->speculative ? (uint64_t)(expect * std::max(1.5, 1.25 * ln->excess)) + (4u << 20) : 0;
         if (spec_cap && sh->spec_shrink > 0) spec_cap = spec_cap / sh->spec_shrink + 1;  // tests: force the retry path
         if (spec_cap >= (1ull << 32)) spec_cap = 0;
@@ -338,6 +370,7 @@ static void lane_main(Lane *ln, Shared *sh) {
         }
         if (!rc && expect > 0) ln->excess = std::max(ln->excess, (double)nhits / expect);
         if (rc) { fail(rc); break; }
+        }  // one-pass unit
         {
             std::lock_guard<std::mutex> lk(sh->mu);
             Batch &b = *sh->batch;

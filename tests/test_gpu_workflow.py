@@ -308,3 +308,27 @@ def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
     monkeypatch.setenv('MIMEO_INDEX_BUDGET_MB', '300')
     assert eng.align_pairs(A, None, sub).tobytes() == ref.tobytes()
     A.close()
+
+
+def test_chunked_units_give_the_same_alignments(eng, monkeypatch):
+    """A unit beyond MIMEO_CHUNK_HITS expected seed hits (default 1.5e9: scaffolds of ~45 Mbp and more) is joined
+    chunk by chunk of the query, followers and candidates resolved once at the end.  Forced here on small
+    scaffolds with long repeat copies (follower chains cross the chunk borders): byte-identical records,
+    and equal to the oracle."""
+    from oracle import oracle as O
+    names, seqs = synth_genome(321, 900_000, 3, repeat_frac=0.3, families=3, cons_len=(2000, 9000), max_div=0.05)
+    A = eng.Genome(names, seqs)
+    pairs = [(0, 1), (1, 1), (2, 0)]
+    whole = eng.align_pairs(A, None, pairs)
+    assert eng.stats()['chunked_units'] == 0 and whole.size > 20
+    for limit in ('2e4', '3e3'):       # ~ 6 and ~ 35 chunks per unit
+        monkeypatch.setenv('MIMEO_CHUNK_HITS', limit)
+        got = eng.align_pairs(A, None, pairs)
+        assert eng.stats()['chunked_units'] == 6
+        assert got.tobytes() == whole.tobytes(), limit
+    monkeypatch.delenv('MIMEO_CHUNK_HITS')
+    cols = ['tstart', 'tend', 'qstart', 'qend', 'score', 'id_n', 'id_d', 'qstrand']
+    exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes())
+    sub = whole[(whole['tid'] == 0) & (whole['qid'] == 1)]
+    assert np.array_equal(np.sort(sub[cols], order=cols), np.sort(exp[cols], order=cols))
+    A.close()
