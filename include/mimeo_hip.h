@@ -129,7 +129,8 @@ typedef struct mimeo_stats {
     uint64_t index_blocks;        /* blocks the pair matrix was cut into so that the seed indexes fit in memory (1 = none) */
     uint64_t lanes;               /* lanes (host thread + stream + work buffers) the call used: fewer for large scaffolds */
     uint64_t chunked_units;       /* units whose query was joined chunk by chunk (more than MIMEO_CHUNK_HITS expected seed hits) */
-    uint64_t reserved[3];
+    uint64_t chunk_splits;        /* chunks halved because their real hit count exceeded the per-chunk budget */
+    uint64_t reserved[2];
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */

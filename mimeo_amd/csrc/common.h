@@ -167,8 +167,10 @@ struct Exclusive {
 };
 // spec_cap = 0: exact (one host round trip for the hit count).  spec_cap > 0: speculative — the buffer holds
 // spec_cap hits, nothing is read back, *nhits is 0 and the count stays on the device (ctx.total_dev()).
+// max_hits (exact mode only): a count beyond it returns MIMEO_SPLIT with *nhits = the count and nothing joined
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex = nullptr, uint64_t spec_cap = 0);
+              JoinTiming *tm, Exclusive *ex = nullptr, uint64_t spec_cap = 0, uint64_t max_hits = ~0ull);
+constexpr int MIMEO_SPLIT = 2;  // internal: a chunk of a chunked unit holds too many hits, the caller halves it
 void join_timing_flush(JoinCtx &ctx);
 constexpr int MIMEO_RETRY_EXACT = 1;  // internal: a speculative unit did not fit its buffers
 

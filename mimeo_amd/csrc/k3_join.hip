@@ -219,7 +219,7 @@ void JoinCtx::release() {
 }
 
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex, uint64_t spec_cap) {
+              JoinTiming *tm, Exclusive *ex, uint64_t spec_cap, uint64_t max_hits) {
     if (!ctx.tile_count) {
         HIP_TRY(hipMalloc((void **)&ctx.tile_count, (NTILE + 2) * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&ctx.tile_base, (NTILE + 2) * sizeof(unsigned long long)));
@@ -253,6 +253,7 @@ int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transiti
         HIP_TRY(hipMemcpyAsync(&total, ctx.tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         *nhits = total;
+        if (total > max_hits) return MIMEO_SPLIT;
         if (total >= (1ull << 32)) {
             set_error("one (target, query, strand) unit yields 2^32 or more seed hits (low-complexity sequence?): not supported");
             return MIMEO_ERR_LIMIT;

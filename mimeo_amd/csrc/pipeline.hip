@@ -322,21 +322,39 @@ static void lane_main(Lane *ln, Shared *sh) {
             const uint32_t nchunks = (uint32_t)std::min(4096.0, std::ceil(expect / (0.67 * chunk_hits)));
             sh->gate.acquire(st);
             ExtChunk ch{1, 0, (uint64_t)(expect / 32.0) + (1u << 20), 0, 0};
-            for (uint32_t c = 0; c < nchunks && !rc; c++) {
-                const uint32_t p0 = (uint32_t)((uint64_t)qv.len * c / nchunks), p1 = (uint32_t)((uint64_t)qv.len * (c + 1) / nchunks);
+            // ranges of query positions still to do (ascending); a range whose real hit count is beyond the
+            // per-chunk budget (repeats, satellites) is halved
+            const uint64_t max_hits = getenv("MIMEO_CHUNK_MAX_HITS") ? (uint64_t)atof(getenv("MIMEO_CHUNK_MAX_HITS")) : (uint64_t)(2.0 * chunk_hits);
+            std::vector<std::pair<uint32_t, uint32_t>> todo;
+            for (uint32_t c = nchunks; c-- > 0;)
+                todo.emplace_back((uint32_t)((uint64_t)qv.len * c / nchunks), (uint32_t)((uint64_t)qv.len * (c + 1) / nchunks));
+            bool any = false;
+            while (!todo.empty() && !rc) {
+                const std::pair<uint32_t, uint32_t> r = todo.back();
+                todo.pop_back();
                 SeedIndex qc;
                 float ms_idx = 0;
                 uint64_t n = 0;
-                if ((rc = build_index(qv, qc, &ms_idx, p0, p1))) break;
-                rc = join_hits(ln->jc, ti, qc.view(), p->transitions, ln->hits, &n, &ln->tm, sh->excl, 0);
-                ch.first = c == 0;
-                ch.last = c + 1 == nchunks;
-                ch.nfollow_before = ch.nfollow_after;
-                if (!rc)
-                    rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, n, p, ln->unit_hsps, &nh, &ln->ms_ext, nullptr,
-                                              nullptr, nullptr, &ch);
-                nhits += n;
+                if ((rc = build_index(qv, qc, &ms_idx, r.first, r.second))) break;
+                rc = join_hits(ln->jc, ti, qc.view(), p->transitions, ln->hits, &n, &ln->tm, sh->excl, 0, max_hits);
                 qc.release();
+                if (rc == MIMEO_SPLIT) {
+                    rc = 0;
+                    if (r.second - r.first < 2) { set_error("one query position yields more seed hits than a chunk may hold"); rc = MIMEO_ERR_LIMIT; break; }
+                    const uint32_t mid = r.first + (r.second - r.first) / 2;
+                    todo.emplace_back(mid, r.second);
+                    todo.emplace_back(r.first, mid);
+                    g_stats.chunk_splits++;
+                    continue;
+                }
+                if (rc) break;
+                ch.first = !any;
+                ch.last = todo.empty();
+                ch.nfollow_before = ch.nfollow_after;
+                rc = ungapped_hsps_device(ln->ew, tv, qv, (const uint2 *)ln->hits.p, n, p, ln->unit_hsps, &nh, &ln->ms_ext, nullptr,
+                                          nullptr, nullptr, &ch);
+                any = true;
+                nhits += n;
             }
             (void)sh->gate.release(st, ln->heavy_end, nullptr);
             sh->cache->token();

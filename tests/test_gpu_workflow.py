@@ -326,6 +326,10 @@ def test_chunked_units_give_the_same_alignments(eng, monkeypatch):
         got = eng.align_pairs(A, None, pairs)
         assert eng.stats()['chunked_units'] == 6
         assert got.tobytes() == whole.tobytes(), limit
+    monkeypatch.setenv('MIMEO_CHUNK_MAX_HITS', '2000')   # chunks whose real hit count is beyond the budget are halved
+    got = eng.align_pairs(A, None, pairs)
+    assert eng.stats()['chunk_splits'] > 10 and got.tobytes() == whole.tobytes()
+    monkeypatch.delenv('MIMEO_CHUNK_MAX_HITS')
     monkeypatch.delenv('MIMEO_CHUNK_HITS')
     cols = ['tstart', 'tend', 'qstart', 'qend', 'score', 'id_n', 'id_d', 'qstrand']
     exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes())
