@@ -158,6 +158,24 @@ def cpu_baseline_rows(seqs, slice_bp=2_000_000):
     return out
 
 
+def reference_tools_check():
+    """probe the box for the reference's external binaries (outside the timed region).  With a
+    real lastz on PATH the A/B diff of scripts/crosscheck_lastz.py is run and summarised; without one the
+    line says that the alignment stages stay parity-unpinned."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import crosscheck_lastz
+    found = crosscheck_lastz.probe()
+    if found['lastz']:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'crosscheck_lastz.py'), '--json'], capture_output=True,
+                               text=True, timeout=600)
+            found['crosscheck'] = json.loads(r.stdout.strip().split('\n')[-1]) if r.returncode == 0 else {'error': r.stderr[-500:]}
+        except Exception as e:  # the probe must never cost the bench line
+            found['crosscheck'] = {'error': repr(e)}
+    return found
+
+
 def pmc_traffic(workload):
     """HBM bytes per seed-scan launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction, calibrated on k3_join_count; profiles/r01_pmc_seed_scan.json)."""
@@ -311,6 +329,7 @@ def main():
         }
         if kind == 'row':
             line['whole_job_s_at_this_rate'] = total_bp / 1e9 / value
+        line['reference_tools'] = reference_tools_check()
         if not args.no_cpu_baseline and dist.world == 1 and B is None:
             line['cpu_baseline'] = cpu_baseline_rows(seqs) if kind == 'row' and nscaf > 1 else cpu_baseline_job(names, seqs, (0, 0), (0, 1))
         print(json.dumps(line))

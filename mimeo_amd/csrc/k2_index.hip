@@ -54,21 +54,31 @@ __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict
 // a small free list that the next build of the same size picks up.
 static DeviceBuf g_hist, g_keys_in, g_keys_out, g_pos_in, g_tmp;
 static std::vector<std::pair<size_t, void *>> g_free_list;
+// The free list has a lock of its own: SeedIndex::release() runs on any thread (a lane giving a chunk index
+// back, the end of a call) while the index builder thread may be inside build_index() taking a buffer.  It is
+// not build_index's mutex: release() is also called with that one held.
+static std::mutex g_free_mu;
 
 static int pool_alloc(void **p, size_t bytes) {
-    for (size_t i = 0; i < g_free_list.size(); i++)
-        if (g_free_list[i].first == bytes) {
-            *p = g_free_list[i].second;
-            g_free_list.erase(g_free_list.begin() + i);
-            return 0;
-        }
+    {
+        std::lock_guard<std::mutex> lk(g_free_mu);
+        for (size_t i = 0; i < g_free_list.size(); i++)
+            if (g_free_list[i].first == bytes) {
+                *p = g_free_list[i].second;
+                g_free_list.erase(g_free_list.begin() + i);
+                return 0;
+            }
+    }
     HIP_TRY(hipMalloc(p, bytes));
     return 0;
 }
 static void pool_free(void *p, size_t bytes) {
     if (!p) return;
-    if (g_free_list.size() >= 512) { (void)hipFree(p); return; }
-    g_free_list.emplace_back(bytes, p);
+    {
+        std::lock_guard<std::mutex> lk(g_free_mu);
+        if (g_free_list.size() < 512) { g_free_list.emplace_back(bytes, p); return; }
+    }
+    (void)hipFree(p);
 }
 
 void SeedIndex::release() {

@@ -32,29 +32,41 @@ __global__ void k7_events(const mimeo_interval *__restrict__ iv, uint64_t n, con
     key[2 * i + 1] = ke; delta[2 * i + 1] = de;
 }
 
-__global__ void k7_regions(const uint64_t *__restrict__ key, const int32_t *__restrict__ depth, uint64_t n,
-                           int32_t min_cov, uint32_t min_len, mimeo_interval *__restrict__ out,
-                           unsigned long long *__restrict__ nout) {
+// flag[i] = 1 for the LAST event of every distinct (chrom, position): depth[i] holds from there to the next position
+__global__ void k7_last_flags(const uint64_t *__restrict__ key, uint64_t n, uint8_t *__restrict__ flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t k = key[i];
-    if (k == ~0ull) return;
-    bool last = (i + 1 == n) || key[i + 1] != k;  // depth[i] holds from this position to the next one
-    if (!last || depth[i] < min_cov) return;
-    uint64_t g = i;  // first event of my position
-    while (g > 0 && key[g - 1] == k) g--;
-    if (g > 0 && depth[g - 1] >= min_cov) return;  // the run started earlier
-    uint64_t j = i + 1;
-    while (j < n) {
-        bool lj = (j + 1 == n) || key[j + 1] != key[j];
-        if (lj && depth[j] < min_cov) break;
-        j++;
+    const uint64_t k = key[i];
+    flag[i] = (k != ~0ull && (i + 1 == n || key[i + 1] != k)) ? 1 : 0;
+}
+// On the distinct positions: a region starts where the depth reaches min_cov and ends where it falls below it.  The
+// depth is 0 behind the last event of a chromosome, so a run never crosses into the next one; runs of equal or
+// different depth >= min_cov that touch are one run by construction (bedtools merge -d 0 joins book-ended intervals).
+__global__ void k7_edge_flags(const int32_t *__restrict__ udep, const unsigned long long *__restrict__ nu_dev, int32_t min_cov,
+                              uint8_t *__restrict__ sflag, uint8_t *__restrict__ eflag, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint64_t nu = *nu_dev;
+    bool s = false, e = false;
+    if (i < nu) {
+        const bool above = udep[i] >= min_cov, prev = i > 0 && udep[i - 1] >= min_cov;
+        s = above && !prev;
+        e = !above && prev;
     }
-    if (j >= n) return;  // cannot happen: depth returns to 0 at the last event of a chromosome
-    uint32_t s = (uint32_t)k, e = (uint32_t)key[j];
+    sflag[i] = s ? 1 : 0;
+    eflag[i] = e ? 1 : 0;
+}
+// starts[j] / ends[j] are the j-th rising / falling edge in (chrom, position) order: region j
+__global__ void k7_regions(const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
+                           const unsigned long long *__restrict__ nreg_dev, uint32_t min_len, mimeo_interval *__restrict__ out,
+                           unsigned long long *__restrict__ nout, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= *nreg_dev) return;
+    const uint64_t ks = starts[i], ke = ends[i];
+    const uint32_t s = (uint32_t)ks, e = (uint32_t)ke;
     if (e - s >= min_len) {
         unsigned long long o = atomicAdd(nout, 1ull);
-        out[o] = mimeo_interval{(uint32_t)(k >> 32), s, e};
+        out[o] = mimeo_interval{(uint32_t)(ks >> 32), s, e};
     }
 }
 
@@ -63,34 +75,61 @@ int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint3
     out.clear();
     if (!n) return 0;
     hipStream_t st = stream();
-    DeviceBuf iv, cl, k1, k2, d1, d2, dep, res, cnt, tmp;
+    DeviceBuf iv, cl, k1, k2, d1, d2, dep, res, cnt, tmp, fl, fl2;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // every return path, the error ones included, gives the buffers and the event pair back
+    struct Cleanup {
+        DeviceBuf *bufs[12];
+        hipEvent_t *a, *b;
+        ~Cleanup() {
+            for (DeviceBuf *x : bufs) x->release();
+            if (*a) (void)hipEventDestroy(*a);
+            if (*b) (void)hipEventDestroy(*b);
+        }
+    } cleanup{{&iv, &cl, &k1, &k2, &d1, &d2, &dep, &res, &cnt, &tmp, &fl, &fl2}, &e0, &e1};
     int rc = 0;
     uint64_t ne = 2 * n;
     if ((rc = iv.reserve(n * sizeof(mimeo_interval))) || (rc = cl.reserve((size_t)(nchrom ? nchrom : 1) * 4)) ||
         (rc = k1.reserve(ne * 8)) || (rc = k2.reserve(ne * 8)) || (rc = d1.reserve(ne * 4)) ||
         (rc = d2.reserve(ne * 4)) || (rc = dep.reserve(ne * 4)) || (rc = res.reserve(n * sizeof(mimeo_interval))) ||
-        (rc = cnt.reserve(8)))
+        (rc = cnt.reserve(32)) || (rc = fl.reserve(ne)) || (rc = fl2.reserve(ne)))
         return rc;
-    hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemcpyAsync(iv.p, h_iv, n * sizeof(mimeo_interval), hipMemcpyHostToDevice, st));
     if (nchrom) HIP_TRY(hipMemcpyAsync(cl.p, h_chrom_len, (size_t)nchrom * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, 32, st));
     HIP_TRY(hipEventRecord(e0, st));
     hipLaunchKernelGGL(k7_events, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const mimeo_interval *)iv.p, n,
                        (const uint32_t *)cl.p, nchrom, (uint64_t *)k1.p, (int32_t *)d1.p);
-    size_t t1 = 0, t2 = 0;
+    // cnt: [0] regions kept, [1] distinct positions, [2] rising edges, [3] falling edges
+    unsigned long long *c_out = (unsigned long long *)cnt.p, *c_nu = c_out + 1, *c_ns = c_out + 2, *c_ne = c_out + 3;
+    uint64_t *ukey = (uint64_t *)k1.p;                    // k1 / d1 are free again once the sort has read them
+    int32_t *udep = (int32_t *)d1.p;
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)k1.p, (uint64_t *)k2.p, (int32_t *)d1.p, (int32_t *)d2.p,
                                       (size_t)ne, 0, 64, st));
     HIP_TRY(rocprim::inclusive_scan(nullptr, t2, (int32_t *)d2.p, (int32_t *)dep.p, (size_t)ne, rocprim::plus<int32_t>(), st));
-    if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc;
+    HIP_TRY(rocprim::select(nullptr, t3, (uint64_t *)k2.p, (uint8_t *)fl.p, ukey, c_nu, (size_t)ne, st));
+    HIP_TRY(rocprim::select(nullptr, t4, (int32_t *)dep.p, (uint8_t *)fl.p, udep, c_nu, (size_t)ne, st));
+    if ((rc = tmp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 16))) return rc;
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)k1.p, (uint64_t *)k2.p, (int32_t *)d1.p, (int32_t *)d2.p,
                                       (size_t)ne, 0, 64, st));
     HIP_TRY(rocprim::inclusive_scan(tmp.p, t2, (int32_t *)d2.p, (int32_t *)dep.p, (size_t)ne, rocprim::plus<int32_t>(), st));
     int32_t cov = min_cov < 1 ? 1 : (int32_t)min_cov;  // genomecov -bg never reports depth 0
-    hipLaunchKernelGGL(k7_regions, dim3((uint32_t)((ne + 255) / 256)), dim3(256), 0, st, (const uint64_t *)k2.p,
-                       (const int32_t *)dep.p, ne, cov, min_len, (mimeo_interval *)res.p, (unsigned long long *)cnt.p);
+    const dim3 grd((uint32_t)((ne + 255) / 256)), blk(256);
+    // distinct positions with the depth that holds behind them; then the rising / falling edges of "depth >= cov".
+    // No thread walks a run: at min_cov 1 with the trivial self alignment a run spans every event of a scaffold.
+    hipLaunchKernelGGL(k7_last_flags, grd, blk, 0, st, (const uint64_t *)k2.p, ne, (uint8_t *)fl.p);
+    HIP_TRY(rocprim::select(tmp.p, t3, (uint64_t *)k2.p, (uint8_t *)fl.p, ukey, c_nu, (size_t)ne, st));
+    HIP_TRY(rocprim::select(tmp.p, t4, (int32_t *)dep.p, (uint8_t *)fl.p, udep, c_nu, (size_t)ne, st));
+    hipLaunchKernelGGL(k7_edge_flags, grd, blk, 0, st, (const int32_t *)udep, (const unsigned long long *)c_nu, cov,
+                       (uint8_t *)fl.p, (uint8_t *)fl2.p, ne);
+    uint64_t *starts = (uint64_t *)k2.p, *ends = (uint64_t *)dep.p;  // dep holds ne * 4 bytes: room for ne / 2 ends (>= one per interval)
+    HIP_TRY(rocprim::select(tmp.p, t3, ukey, (uint8_t *)fl.p, starts, c_ns, (size_t)ne, st));
+    HIP_TRY(rocprim::select(tmp.p, t3, ukey, (uint8_t *)fl2.p, ends, c_ne, (size_t)ne, st));
+    hipLaunchKernelGGL(k7_regions, grd, blk, 0, st, (const uint64_t *)starts, (const uint64_t *)ends,
+                       (const unsigned long long *)c_ns, min_len, (mimeo_interval *)res.p, c_out, ne);
     HIP_TRY(hipEventRecord(e1, st));
     unsigned long long m = 0;
     HIP_TRY(hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));
@@ -106,9 +145,6 @@ int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint3
         HIP_TRY(hipEventElapsedTime(&t, e0, e1));
         *ms += t;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    for (DeviceBuf *b : {&iv, &cl, &k1, &k2, &d1, &d2, &dep, &res, &cnt, &tmp}) b->release();
     return 0;
 }
 

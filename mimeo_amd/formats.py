@@ -12,9 +12,10 @@ TAB_HEADER = '#name1\tstrand1\tstart1\tend1\tname2\tstrand2\tstart2+\tend2+\tsco
 GFF_HEADER = '##gff-version 3\n#seqid\tsource\ttype\tstart\tend\tscore\tstrand\tphase\tattributes'  # wrappers.py:1153
 
 
-def read_fasta(path):
+def read_fasta(path, headers=None):
     """FASTA -> (ids, [uint8 arrays]).  id = first word of the header, like Biopython's rec.id
-    used by the reference (utils.py:307, :549)."""
+    used by the reference (utils.py:307, :549).  `headers` (a list) receives the full header lines
+    (Biopython's rec.description: what SeqIO.write puts behind '>')."""
     names, seqs, cur = [], [], None
     with open(path, 'rb') as f:
         data = f.read()
@@ -23,6 +24,8 @@ def read_fasta(path):
         header = block if nl < 0 else block[:nl]
         body = b'' if nl < 0 else block[nl + 1:]
         names.append(header.split()[0].decode() if header.split() else '')
+        if headers is not None:
+            headers.append(header.rstrip(b'\r').decode())
         seqs.append(np.frombuffer(body.translate(None, b'\n\r \t'), dtype=np.uint8))
     return names, seqs
 

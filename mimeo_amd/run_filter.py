@@ -39,7 +39,8 @@ def mainArgs(argv=None):
 def filter_fasta(infile, outfile, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, verbose=False):
     """wrappers.py:265-377 trfFasta; returns the ids kept (in file order)."""
     G = engine.Genome.from_fasta(infile)
-    names, seqs = formats.read_fasta(infile)  # the text is needed again to write the survivors
+    headers = []
+    names, seqs = formats.read_fasta(infile, headers)  # the text is needed again to write the survivors
     iv = np.array([(i, 0, ln) for i, ln in enumerate(G.lengths)], dtype=np.uint32).reshape(-1, 3)
     masked = engine.tandem_masked(G, iv, tmatch, tmismatch, tminscore, tmaxperiod)
     G.close()
@@ -47,9 +48,10 @@ def filter_fasta(infile, outfile, tmatch=2, tmismatch=7, tminscore=50, tmaxperio
     for n, s, m in zip(names, seqs, masked.tolist()):
         if len(s) == 0:
             continue  # the reference divides by len(rec.seq); an empty record cannot pass
-        # K8 counts masked ACGT-or-N positions of tandem segments; Ns outside them count as well,
-        # as rec.seq.count('N') does on TRF's masked output
-        n_count = int(((s == ord('N')) | (s == ord('n'))).sum())
+        # K8 counts masked ACGT-or-N positions of tandem segments; Ns outside them count as well, as
+        # rec.seq.count('N') does on TRF's masked output (wrappers.py:369: upper-case N only, so a
+        # soft-masked record with 'n' runs is not penalised for them)
+        n_count = int((s == ord('N')).sum())
         pct = min(len(s), m + n_count) / len(s) * 100
         if verbose:
             logging.info('%s\tlen %d\tmasked %.1f%%', n, len(s), pct)
@@ -57,9 +59,9 @@ def filter_fasta(infile, outfile, tmatch=2, tmismatch=7, tminscore=50, tmaxperio
             keep.append(n)
     kept = set(keep)
     with open(outfile, 'wb') as f:
-        for n, s in zip(names, seqs):
+        for n, hd, s in zip(names, headers, seqs):
             if n in kept:
-                f.write(b'>' + n.encode() + b'\n')
+                f.write(b'>' + hd.encode() + b'\n')  # SeqIO.write emits '>id description' (wrappers.py:373-377)
                 b = s.tobytes()
                 for i in range(0, len(b), 60):
                     f.write(b[i:i + 60] + b'\n')

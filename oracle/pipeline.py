@@ -165,3 +165,19 @@ def tandem_masked(seq, start, end, match=2, mismatch=7, minscore=50, maxperiod=5
             for k in range(seg, min(L, bestend + p)):
                 masked[k] = 1
     return sum(masked)
+
+
+def trf_filter(rows, seq_of, prefix=None, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, masked_fn=None):
+    """wrappers.py:120-262 trfFilter with `tandem_masked` in TRF's place: slice seq[int(tStart):int(tEnd)]
+    of the origin-one start (wrappers.py:190), keep while masked / len * 100 < maxtandem (:237-240), then the
+    string sort and renumbering of :243-259.  rows: import_align rows; seq_of: name -> bytes."""
+    fn = masked_fn or tandem_masked
+    keep = []
+    for r in rows:
+        s, e = int(r[2]), min(int(r[3]), len(seq_of[r[0]]))
+        if e - s > 0 and fn(seq_of[r[0]], s, e, tmatch, tmismatch, tminscore, tmaxperiod) / (e - s) * 100 < float(maxtandem):
+            keep.append(r[:10])
+    keep.sort(key=lambda f: (f[0], f[2], f[3], f[1]))
+    width = len(str(len(keep)))
+    pre = str(prefix) if prefix else 'BHit'
+    return [f + ['%s_%s' % (pre, str(i).zfill(width))] for i, f in enumerate(keep, 1)]

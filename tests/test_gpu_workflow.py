@@ -316,6 +316,8 @@ def test_chunked_units_give_the_same_alignments(eng, monkeypatch):
     scaffolds with long repeat copies (follower chains cross the chunk borders): byte-identical records,
     and equal to the oracle."""
     from oracle import oracle as O
+    for var in ('MIMEO_CHUNK_HITS', 'MIMEO_CHUNK_MAX_HITS'):  # a sweep that exported them must not leak into the baseline run
+        monkeypatch.delenv(var, raising=False)
     names, seqs = synth_genome(321, 900_000, 3, repeat_frac=0.3, families=3, cons_len=(2000, 9000), max_div=0.05)
     A = eng.Genome(names, seqs)
     pairs = [(0, 1), (1, 1), (2, 0)]

@@ -71,3 +71,25 @@ def test_all_pairs_order():
     from mimeo_amd import workflow
     assert workflow.all_pairs(2) == [(0, 0), (0, 1), (1, 0), (1, 1)]
     assert workflow.all_pairs(2, 3) == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]
+
+
+def test_crosscheck_lastz_probe_and_row_diff(tmp_path):
+    """scripts/crosscheck_lastz.py: without a lastz binary it reports 'parity unpinned' and exits 0; its row
+    diff tells identical rows from rows that only agree on coordinates; the argv is the reference's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'scripts'))
+    import crosscheck_lastz as X
+    found = X.probe(str(tmp_path / 'no_such_lastz'))
+    assert found['lastz'] is None and found['status'] == 'lastz absent: parity unpinned'
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'crosscheck_lastz.py'), '--lzpath', str(tmp_path / 'nope')],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == 'lastz absent: parity unpinned'
+    argv = X.reference_argv('t.fa', 'q.fa', 'o.tab')
+    assert argv[:3] == ['t.fa', 'q.fa', '--entropy'] and '--hspthresh=3000' in argv and argv[-2:] == ['--output=o.tab', '--verbosity=0']
+    row = lambda s1, e1, s2, e2, sc, idt: '\t'.join(['t', '+', str(s1), str(e1), str(e1 - s1 + 1), 'q', '+', str(s2), str(e2), str(e2 - s2 + 1), str(sc), '90/100', idt])
+    real = [row(1, 100, 5, 104, 9000, '90.0%'), row(200, 300, 7, 107, 8000, '90.0%'), row(400, 500, 1, 101, 7000, '90.0%')]
+    ours = [row(1, 100, 5, 104, 9000, '90.0%'), row(200, 300, 7, 107, 8100, '90.0%'), row(600, 700, 1, 101, 7000, '90.0%')]
+    d = X.compare(real, ours)
+    assert d == {'rows_lastz': 3, 'rows_ours': 3, 'identical': 1, 'same_coordinates_other_score': 1, 'only_lastz': 1, 'only_ours': 1}
