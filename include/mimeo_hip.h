@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MIMEO_ABI_VERSION 1
+#define MIMEO_ABI_VERSION 2
 
 enum {
     MIMEO_OK = 0,
@@ -116,21 +116,22 @@ typedef struct mimeo_stats {
     uint64_t alignments;
     uint64_t query_bases_scanned; /* sum over pair-strands of Lq                           */
     uint64_t scan_bytes_algorithmic; /* SURVEY §8(d) B_scan summed over pair-strands       */
-    uint64_t scan_bytes_kernel;   /* compulsory bytes of the index-join kernel  */
+    uint64_t scan_bytes_kernel;   /* compulsory bytes of the seed-scan kernel   */
     double ms_index;              /* HIP-event time in the index-build kernels              */
-    double ms_scan;               /* HIP-event time in the seed-scan (count+fill) kernels   */
-    double ms_extend;             /* ungapped extension + resolution                       */
+    double ms_scan;               /* HIP-event time of the heavy phase: the fused seed-scan / pre-filter / walk kernels (K34) */
+    double ms_extend;             /* the tails of the gap-free stage, once per batch: long walks, follower sort + resolution, entropy */
     double ms_chain;
     double ms_gapped;
     double ms_collapse;
     double ms_total;              /* host wall time of the call                            */
-    uint64_t scan_launches;       /* number of seed-scan fill launches timed in ms_scan_fill */
-    double ms_scan_fill;          /* HIP-event time of the fill kernel alone (the roofline kernel) */
+    uint64_t scan_launches;       /* number of seed-scan kernel launches (one per unit) timed in ms_scan_fill */
+    double ms_scan_fill;          /* HIP-event time of the seed-scan kernels (K34, the roofline kernel), back to back per batch */
     uint64_t index_blocks;        /* blocks the pair matrix was cut into so that the seed indexes fit in memory (1 = none) */
-    uint64_t lanes;               /* lanes (host thread + stream + work buffers) the call used: fewer for large scaffolds */
-    uint64_t chunked_units;       /* units whose query was joined chunk by chunk (more than MIMEO_CHUNK_HITS expected seed hits) */
-    uint64_t chunk_splits;        /* chunks halved because their real hit count exceeded the per-chunk budget */
-    uint64_t reserved[2];
+    uint64_t batches;             /* batches of units the call was worked off in (tails, chain and gapped stage run once per batch) */
+    uint64_t queue_reruns;        /* batches repeated because a queue sized for random sequence overflowed (repeat-rich units) */
+    uint64_t walked_hits;         /* seed hits the pre-filter could not dismiss: walked exactly */
+    uint64_t followers;           /* hits with an earlier seed hit of their diagonal in reach: resolved after one sort per batch */
+    uint64_t reserved[1];
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */
@@ -190,7 +191,8 @@ int mimeo_genome_name(const mimeo_genome *g, uint32_t scaf, const char **name);
  * of run_jobs.sh (call site wrappers.py:1028-1031); mimeo_align_pairs builds the index of a
  * scaffold strand once per call and, by default, gives it back when the call returns.  With
  * keep != 0 the indexes that later calls build for scaffolds of `g` stay attached to the handle
- * (64 MiB + 4 bytes per base and strand: a 1 Gbp genome, both strands, is 21 GB of the 288 GB)
+ * (64 MiB + 52 bytes per base and strand — offsets, positions and the seed frames the fused seed-scan
+ * kernel streams: a 1 Gbp genome, both strands, is 117 GB of the 288 GB)
  * and are reused by every later call, so a job may be issued as several calls (one per target
  * scaffold, say) without paying for the tables again.  mimeo_genome_drop_indexes releases the
  * indexes (both strands) of the listed scaffolds, or all of them when n == 0;

@@ -254,26 +254,28 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
     auto t0 = std::chrono::steady_clock::now();
     memset(&g_stats, 0, sizeof g_stats);
     const Scaffold &ts = T->scaf[tid], &qs = Q->scaf[qid];
-    StrandView tv = ts.fwd.view(true), qv = (qstrand ? qs.rc : qs.fwd).view(false);
     SeedIndex it, iq;
-    float ms_index = 0, ms_ext = 0;
-    DeviceBuf hits, hsps;
-    uint64_t n = 0, nh = 0;
-    JoinTiming tm;
+    float ms_index = 0;
     mimeo_hsp *h = nullptr;
+    uint64_t nh = 0;
+    ExtStats est;
     do {
-        if ((rc = build_index(tv, it, &ms_index))) break;
-        if ((rc = build_index(qv, iq, &ms_index))) break;
-        static JoinCtx jc;
-        static ExtWork ew;
-        if ((rc = join_hits(jc, it.view(), iq.view(), p->transitions, hits, &n, &tm))) break;
-        if ((rc = ungapped_hsps_device(ew, tv, qv, (const uint2 *)hits.p, n, p, hsps, &nh, &ms_ext))) break;
+        // the production path of mimeo_align_pairs up to K4, on a batch of one unit
+        std::vector<UnitWork> work(1);
+        memset(&work[0], 0, sizeof(UnitWork));
+        work[0].d.T = ts.fwd.view(true);
+        work[0].d.Q = (qstrand ? qs.rc : qs.fwd).view(false);
+        work[0].d.same = (work[0].d.T.pw == work[0].d.Q.pw && work[0].d.T.len == work[0].d.Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1u : 0u;
+        if ((rc = build_index(work[0].d.T, it, &ms_index))) break;
+        if ((rc = build_index(work[0].d.Q, iq, &ms_index))) break;
+        work[0].ti = it.view();
+        work[0].qi = iq.view();
+        std::vector<std::vector<mimeo_hsp>> per_unit;
+        if ((rc = ungapped_units(work, p, &per_unit, &est))) break;
+        nh = per_unit[0].size();
         h = (mimeo_hsp *)malloc((nh ? nh : 1) * sizeof(mimeo_hsp));
         if (!h) { set_error("host allocation failed"); rc = MIMEO_ERR_NOMEM; break; }
-        if (nh) {
-            hipError_t e = hipMemcpy(h, hsps.p, nh * sizeof(mimeo_hsp), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { rc = hip_fail(e, "hipMemcpy(hsps)", __FILE__, __LINE__); break; }
-        }
+        if (nh) memcpy(h, per_unit[0].data(), nh * sizeof(mimeo_hsp));
         std::sort(h, h + nh, [](const mimeo_hsp &a, const mimeo_hsp &b) {
             int64_t da = (int64_t)a.tstart - a.qstart, db = (int64_t)b.tstart - b.qstart;
             if (da != db) return da < db;
@@ -281,19 +283,25 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
             return a.length < b.length;
         });
     } while (0);
-    hits.release(); hsps.release(); it.release(); iq.release();
+    it.release(); iq.release();
     if (rc) { free(h); return rc; }
     *out = h;
     *nout = nh;
     g_stats.pair_strands = 1;
-    g_stats.seed_hits = n;
+    g_stats.seed_hits = est.seed_hits;
     g_stats.hsps = nh;
     g_stats.query_bases_scanned = qs.len;
+    g_stats.scan_bytes_algorithmic = est.scan_bytes_algorithmic;
+    g_stats.scan_bytes_kernel = est.scan_bytes_kernel;
+    g_stats.walked_hits = est.walked;
+    g_stats.followers = est.followers;
+    g_stats.queue_reruns = est.reruns;
+    g_stats.batches = 1;
     g_stats.ms_index = ms_index;
-    g_stats.ms_scan = tm.ms_count + tm.ms_fill;
-    g_stats.ms_scan_fill = tm.ms_fill;
-    g_stats.scan_launches = 1;
-    g_stats.ms_extend = ms_ext;
+    g_stats.ms_scan = est.ms_heavy;
+    g_stats.ms_scan_fill = est.ms_heavy;
+    g_stats.scan_launches = est.heavy_launches;
+    g_stats.ms_extend = est.ms_tails;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MIMEO_OK;
 }

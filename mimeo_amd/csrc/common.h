@@ -59,9 +59,24 @@ struct StrandView {
     uint32_t has_n;        // the strand holds at least one non-ACGT base
 };
 
+// Seed frames (K2, read by the fused seed-scan / extension kernel K34): every index entry carries the 192 bases
+// [p - FRAME_LEFT, p - FRAME_LEFT + 192) around its seed start p as two bit planes brought into ONE alignment (bit 0 =
+// base p - FRAME_LEFT), 12 words = three uint4 {lo0..lo3} {lo4,lo5,hi0,hi1} {hi2..hi5}.  Target and query frames of
+// a seed hit then XOR word by word with no shifting, and every shift in the pre-filter is a compile-time constant.
+// The seed end p + 19 sits at frame bit 128: the left walk (through the seed) owns bits 127 .. 32 (96 steps, six
+// half-word blocks), the right walk bits 128 .. 191 (64 steps), and bits 13 .. 31 only serve the seed windows that
+// END where the last left steps arrive.  Bit 31 of pos[] is set for an entry whose frame holds a non-ACGT base (the
+// frame shows it as A): such a hit always goes to the exact walk.
+constexpr int FRAME_LEFT = 109;            // frame bit 0 = base p - 109
+constexpr int FRAME_WORDS = 6;             // per plane
+constexpr uint32_t POS_MASK = 0x7FFFFFFFu;
+constexpr uint32_t POS_NFLAG = 0x80000000u;
+
 struct IndexView {
     const uint32_t *off;  // NBUCKET + 1
-    const uint32_t *pos;
+    const uint32_t *pos;  // bit 31: the entry's frame holds an N (POS_NFLAG)
+    const uint4 *fr;      // 3 parts per entry, part k of entry i at fr[k * fr_stride + i]
+    uint32_t fr_stride;
     uint32_t n;  // number of indexed positions
 };
 
@@ -79,11 +94,14 @@ struct Strand {
 struct SeedIndex {
     uint32_t *off = nullptr;
     uint32_t *pos = nullptr;
-    uint32_t n = 0;
-    size_t pos_bytes = 0;  // allocation size of pos (free-list key)
-    IndexView view() const { return IndexView{off, pos, n}; }
+    uint4 *fr = nullptr;
+    uint32_t n = 0, fr_stride = 0;
+    size_t pos_bytes = 0, fr_bytes = 0;  // allocation sizes (free-list keys)
+    IndexView view() const { return IndexView{off, pos, fr, fr_stride, n}; }
     void release();
 };
+// device bytes of the seed index of one strand of `len` bases: offsets, positions, frames
+inline uint64_t seed_index_bytes(uint64_t len) { return ((uint64_t)NBUCKET + 2) * 4 + len * (4 + 48); }
 
 struct Scaffold {
     uint64_t len = 0;
@@ -137,67 +155,46 @@ struct JoinTiming { float ms_count = 0, ms_fill = 0; };
 struct JoinCtx {
     unsigned long long *tile_count = nullptr, *tile_base = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    JoinTiming *pending_tm = nullptr;  // a speculative launch whose event times have not been read yet
-    const unsigned long long *total_dev() const { return tile_base + NTILE; }  // hit count of the last join
     void release();
 };
-// Lets one kernel run alone on the device while several lanes (streams) are active: begin() makes
-// `mine` wait for everything the other streams have been given so far, end() makes the other
-// streams wait for what `mine` was given in between.  Used for the bandwidth-bound seed-scan fill.
-struct Exclusive {
-    std::mutex mu;
-    int n = 0;
-    hipStream_t st[8];
-    hipEvent_t reached[8], done[8];
-    int index_of(hipStream_t s) const { for (int i = 0; i < n; i++) if (st[i] == s) return i; return -1; }
-    void begin(hipStream_t mine) {
-        mu.lock();
-        for (int i = 0; i < n; i++)
-            if (st[i] != mine) { (void)hipEventRecord(reached[i], st[i]); (void)hipStreamWaitEvent(mine, reached[i], 0); }
-    }
-    void end(hipStream_t mine) {
-        int me = index_of(mine);
-        if (me >= 0) {
-            (void)hipEventRecord(done[me], mine);
-            for (int i = 0; i < n; i++)
-                if (st[i] != mine) (void)hipStreamWaitEvent(st[i], done[me], 0);
-        }
-        mu.unlock();
-    }
-};
-// spec_cap = 0: exact (one host round trip for the hit count).  spec_cap > 0: speculative — the buffer holds
-// spec_cap hits, nothing is read back, *nhits is 0 and the count stays on the device (ctx.total_dev()).
-// max_hits (exact mode only): a count beyond it returns MIMEO_SPLIT with *nhits = the count and nothing joined
+// exact mode: one host round trip for the hit count, then the fill (stage entry point, A/B heavy path)
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex = nullptr, uint64_t spec_cap = 0, uint64_t max_hits = ~0ull);
-constexpr int MIMEO_SPLIT = 2;  // internal: a chunk of a chunked unit holds too many hits, the caller halves it
-void join_timing_flush(JoinCtx &ctx);
-constexpr int MIMEO_RETRY_EXACT = 1;  // internal: a speculative unit did not fit its buffers
+              JoinTiming *tm);
 
-// K4: seed hits -> HSPs (k4_extend.hip); out_hsps holds mimeo_hsp records on the device
-struct ExtCounters;
-struct ExtWork {  // per-lane work state of K4
-    ExtCounters *ctr = nullptr;  // device
-    DeviceBuf cand, fkey, fkey2, fprev, fprev2, longq, medq, flags, segs, tmp, nsel, bigseg;
+// K4: seed hits -> HSPs for a BATCH of units (k4_extend.hip, k34_fused.hip).  One unit = one (target scaffold,
+// query scaffold, strand); the device table of UnitDesc is what every K4 kernel looks its two strands up in.
+struct UnitDesc {
+    StrandView T, Q;
+    uint32_t same;  // target and query are the same strand of the same scaffold: diagonal 0 belongs to k4_diag0
+    uint32_t pad[3];
+};
+struct UnitWork {  // host side: a unit with the seed indexes its heavy kernel reads
+    UnitDesc d;
+    IndexView ti, qi;
+};
+struct ExtStats {
+    uint64_t seed_hits = 0, walked = 0, followers = 0, candidates = 0, reruns = 0;
+    uint64_t scan_bytes_algorithmic = 0, scan_bytes_kernel = 0, heavy_launches = 0;
+    float ms_heavy = 0, ms_walk = 0, ms_tails = 0;  // ms_walk: the exact walks of the walk queue (part of ms_tails)
+};
+// The extension stage of one batch: heavy kernel per unit (K34 fused seed scan + pre-filter + exact walks; or, for
+// A/B checks, the stand-alone K3 join + K4 fast kernel of round 1) appending to batch-wide queues, then the tails ONCE
+// per batch: walks beyond the frame, k4_diag0 of the self units, ONE radix sort of the followers of all units,
+// segment resolution, entropy.  Two host synchronisations per batch.  Leaves nhsp HSPs in hsps / hsp_unit (device).
+struct ExtBatch {
+    DeviceBuf units, ctr, cand, fkey, fkey2, fprev, fprev2, medq, medu, longq, longu, walkq, walku, flags, segs, tmp, nsel, bigseg, hsps,
+        hsp_unit, unit_hits, tile_hits, selfs, hits;
+    JoinCtx jc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side = nullptr;      // k4_diag0 of the self units runs beside the heavy kernels
+    hipEvent_t side_done = nullptr;
+    std::vector<unsigned long long> h_unit_hits;
+    double boost = 1.0;  // queue sizing: largest excess over the random-sequence shares seen so far
+    int run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp, ExtStats *st);
     void release();
 };
-// `after_fast` (optional) is called once, right after the fast kernel of the first attempt has been
-// launched: the point where a concurrent lane may start its own heavy phase.
-// d_nhits != null: speculative — `nhits` is the capacity of `hits`, the real count is read by the kernels
-// from *d_nhits and returned in *nhits_out; MIMEO_RETRY_EXACT if it exceeded the capacity.
-// `chunk` (optional): the unit's hits arrive in several calls (a very large unit whose query is joined chunk by chunk,
-// pipeline.hip).  Heads are decided from the sequences alone and are finished per call; followers and candidates
-// accumulate in W and are resolved in the call flagged `last` — a follower chain may cross a chunk border.
-struct ExtChunk {
-    int first, last;
-    uint64_t cand_cap;        // candidate capacity of the whole unit (no rerun in chunked mode)
-    uint64_t nfollow_before;  // followers gathered by the earlier chunks (in)
-    uint64_t nfollow_after;   // ... including this one (out)
-};
-int ungapped_hsps_device(ExtWork &W, const StrandView &T, const StrandView &Q, const uint2 *hits, uint64_t nhits,
-                         const mimeo_params *p, DeviceBuf &out_hsps, uint64_t *nhsp, float *ms,
-                         const std::function<void()> *after_fast = nullptr, const unsigned long long *d_nhits = nullptr,
-                         uint64_t *nhits_out = nullptr, ExtChunk *chunk = nullptr);
+// largest batch the follower key can name for scaffolds of these lengths (unit bits = 64 - end bits - diagonal bits)
+uint32_t ext_batch_max_units(uint64_t max_tlen, uint64_t max_qlen);
 
 // K5/K6: one group = one (target scaffold, query scaffold, strand) with its HSP range
 constexpr int MAX_BATCH = 32;
@@ -211,14 +208,14 @@ struct Group {
     uint32_t batch[MAX_BATCH];
 };
 // K5 (k5_chain.hip): sort + chain + anchor order for every group
-int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps, int do_chain,
-                 mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order);
+int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
+                 int do_chain, mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order);
 // K6 (k6_gapped.hip): anchors -> gapped alignments; alignments of group g land at
 // d_aln[hsp_begin .. hsp_begin + naln)
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln);
 // chain + gapped extension of every group (pipeline.hip)
-int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps,
+int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
                         const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,
                         float *ms_gapped);
 
@@ -231,6 +228,8 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
 
 void release_pipeline_buffers();  // pipeline.hip
+int ungapped_units(const std::vector<UnitWork> &work, const mimeo_params *p, std::vector<std::vector<mimeo_hsp>> *per_unit,
+                   ExtStats *st);  // pipeline.hip: the extension stage of a batch, HSPs per unit on the host
 int build_kept_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n);  // pipeline.hip
 
 // K8: tandem scorer (k8_tandem.hip); host in, host out

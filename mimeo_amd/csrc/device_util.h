@@ -4,6 +4,12 @@
 
 namespace mimeo {
 
+// 12 care bits of the 19-bit window of the 12of19 seed 1110100110010101111: offsets {0,1,2,4,7,8,11,13,15,16,17,18}
+__device__ __forceinline__ uint32_t pext12(uint32_t x) {
+    return (x & 0x7u) | ((x >> 1) & 0x8u) | ((x >> 3) & 0x30u) | ((x >> 5) & 0x40u) | ((x >> 6) & 0x80u) |
+           ((x >> 7) & 0xF00u);
+}
+
 struct Win32 { uint32_t lo, hi, nm, sv; };
 struct Win64 { uint64_t lo, hi, nm, sv; };
 

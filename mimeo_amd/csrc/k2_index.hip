@@ -14,15 +14,9 @@
 
 #include <rocprim/rocprim.hpp>
 
-#include "common.h"
+#include "device_util.h"
 
 namespace mimeo {
-
-// 12 care bits of the 19-bit window: offsets {0,1,2,4,7,8,11,13,15,16,17,18}
-__device__ __forceinline__ uint32_t pext12(uint32_t x) {
-    return (x & 0x7u) | ((x >> 1) & 0x8u) | ((x >> 3) & 0x30u) | ((x >> 5) & 0x40u) | ((x >> 6) & 0x80u) |
-           ((x >> 7) & 0xF00u);
-}
 
 // one thread per 32 start positions: keys (1<<24 for "no seed here") + histogram
 __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict__ keys,
@@ -47,6 +41,40 @@ __global__ void k2_seed_keys(StrandView s, uint32_t nwords, uint32_t *__restrict
         keys[p] = key;
         posv[p] = p;
     }
+}
+
+// Seed frames (common.h): one thread per index entry gathers the seven words around its seed start from the
+// two-plane copy, brings them into the frame alignment (bit 0 = base p - FRAME_LEFT) and stores the twelve words;
+// an N anywhere in the frame sets bit 31 of pos[].  Once per strand and job: the fused seed-scan kernel then
+// streams the frames of both sides of every seed hit from contiguous memory instead of gathering 13 words per HIT.
+__global__ void k2_frames(StrandView s, uint32_t *__restrict__ pos, uint32_t n, uint4 *__restrict__ fr, uint32_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pos[i] & POS_MASK;
+    const int32_t b0 = (int32_t)p - FRAME_LEFT;   // may be negative: PLANE_PAD zero words lie in front of word 0
+    const int32_t w = b0 >> 5;
+    const uint32_t sh = (uint32_t)b0 & 31u;
+    uint32_t lo[FRAME_WORDS + 1], hi[FRAME_WORDS + 1], nm = 0;
+    if (s.has_n) {
+        uint32_t z[FRAME_WORDS + 1];
+#pragma unroll
+        for (int k = 0; k <= FRAME_WORDS; k++) { const uint4 v = s.pw[w + k]; lo[k] = v.x; hi[k] = v.y; z[k] = v.z; }
+#pragma unroll
+        for (int k = 0; k < FRAME_WORDS; k++) nm |= __builtin_amdgcn_alignbit(z[k + 1], z[k], sh);
+    } else {
+#pragma unroll
+        for (int k = 0; k <= FRAME_WORDS; k++) { const uint2 v = s.p2[w + k]; lo[k] = v.x; hi[k] = v.y; }
+    }
+    uint32_t fl[FRAME_WORDS], fh[FRAME_WORDS];
+#pragma unroll
+    for (int k = 0; k < FRAME_WORDS; k++) {
+        fl[k] = __builtin_amdgcn_alignbit(lo[k + 1], lo[k], sh);
+        fh[k] = __builtin_amdgcn_alignbit(hi[k + 1], hi[k], sh);
+    }
+    fr[i] = make_uint4(fl[0], fl[1], fl[2], fl[3]);
+    fr[(size_t)stride + i] = make_uint4(fl[4], fl[5], fh[0], fh[1]);
+    fr[2 * (size_t)stride + i] = make_uint4(fh[2], fh[3], fh[4], fh[5]);
+    if (nm) pos[i] = p | POS_NFLAG;
 }
 
 // Device allocations are slow (tens to hundreds of microseconds each) and an index build used to do
@@ -84,9 +112,11 @@ static void pool_free(void *p, size_t bytes) {
 void SeedIndex::release() {
     pool_free(off, ((size_t)NBUCKET + 2) * 4);
     pool_free(pos, pos_bytes);
+    pool_free(fr, fr_bytes);
     off = pos = nullptr;
-    n = 0;
-    pos_bytes = 0;
+    fr = nullptr;
+    n = fr_stride = 0;
+    pos_bytes = fr_bytes = 0;
 }
 
 int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0, uint32_t p1) {
@@ -110,6 +140,9 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0, uin
     if ((rc = pool_alloc((void **)&out.off, ((size_t)NBUCKET + 2) * 4))) return rc;
     out.pos_bytes = n * 4;
     if ((rc = pool_alloc((void **)&out.pos, out.pos_bytes))) return rc;
+    out.fr_bytes = n * 48;
+    out.fr_stride = (uint32_t)n;
+    if ((rc = pool_alloc((void **)&out.fr, out.fr_bytes))) return rc;
     if (nwords)
         hipLaunchKernelGGL(k2_seed_keys, dim3((nwords + 255) / 256), dim3(256), 0, stream(), s, nwords, keys_in,
                            pos_in, hist, p0, p1);
@@ -130,6 +163,9 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0, uin
                                           stream()));
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, out.off + NBUCKET, 4, hipMemcpyDeviceToHost, stream()));
+    // the entries behind `total` (positions without a seed word, key 2^24) are never read; their frames are built
+    // too rather than paying a host round trip for the count first
+    if (len) hipLaunchKernelGGL(k2_frames, dim3((len + 255) / 256), dim3(256), 0, stream(), s, out.pos, len, out.fr, out.fr_stride);
     HIP_TRY(hipEventRecord(e1, stream()));
     HIP_TRY(hipStreamSynchronize(stream()));
     out.n = total;

@@ -1,0 +1,327 @@
+// K34 — seed scan and pre-filter of one unit in ONE kernel (SURVEY §8a A7 + A8: lastz's query scan with 13 probes per
+// base and the first look at every seed hit; reference call site src/mimeo/wrappers.py:1025-1037,
+// `--step=1 --strand=both --gfextend --entropy --hspthresh=H`).
+//
+// Round 1 materialised the hit flood: K3 wrote 77.8 M (tpos, qpos) records per 10 Mbp x 10 Mbp unit (0.9 GB of
+// stores for 0.62 GB of records), K4 read them back and gathered 13 eight-byte words around every hit through L2
+// — to prove for 95 % of them that nothing comes of them.  Here no hit is stored unless it matters:
+//   * both seed indexes are CSR in the transition-closed key layout (common.h): a workgroup owns one tile of 4096
+//     keys, stages the query tile's offsets in LDS (16 KiB) and resolves all 13 probes of a word there (K3's join);
+//   * every index entry carries its seed FRAME (K2: 192 bases around the seed start, both planes, one common
+//     alignment), so a tile's frames are contiguous: the query frames are STREAMED into LDS, coalesced, in segments
+//     of QSEG entries, and each wavefront keeps the frames of 64 target entries in registers (one entry per lane,
+//     the next chunk's already in flight);
+//   * a wavefront enumerates the (target entry, query entry) pairs of its chunk into a small LDS queue of
+//     descriptors (prefix sum of the per-entry counts: full wavefronts whatever the per-entry fan-out, which is
+//     Poisson(7.8) on a C4 unit); a lane takes one pair, fetches the target frame from its owner lane
+//     (ds_bpermute) and the query frame from LDS, and runs the pre-filter: twelve XORs bring the two frames
+//     together, every shift of the popcount bounds and of the earlier-seed-hit test is a compile-time constant;
+//   * the ~1.5 % of the pairs the filter cannot dismiss go, compacted per wavefront (ballot + prefix count), to the
+//     batch's walk queue (k4_walk_queue: the exact walk, once per batch).
+// HBM traffic per unit: the two offset arrays, and positions + frames of both sides ONCE (52 bytes per entry).
+#include <cstdio>
+#include <cstdlib>
+
+#include "k4_device.h"
+
+namespace mimeo {
+
+constexpr uint32_t TCH = 64;      // target entries per wavefront and chunk: one per lane
+constexpr uint32_t DQ = 256;      // pair descriptors per wavefront and round
+constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CARE19
+
+struct FusedArgs {
+    IndexView T, Q;
+    ExtQueues q;
+    uint32_t unit, same;
+    int xdrop, hspthresh, transitions;
+    uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on, 8 = count the reasons
+};
+
+// prefix-score bounds of a 16-step block (k4_device.h, bound_window): v / dh / cg = the block's columns in the low
+// half-word
+__device__ __forceinline__ void bound_block(Bound &B, uint32_t v, uint32_t dh, uint32_t cg, int xdrop) {
+    const uint32_t b = v & dh, a = cg & ~(v | dh);
+    const int32_t dv = __popc(v), db = __popc(b), dt = __popc(dh) - db, da = __popc(a);
+    B.ub = max(B.ub, B.U + 100 * (16 - dv - dt));
+    B.U += 91 * 16 + 9 * da - 122 * dt - 205 * dv - 9 * db;
+    B.nb += db;
+    B.stop = B.stop || (B.U + xdrop < B.lomax);
+    B.lomax = max(B.lomax, B.U - 2 * B.nb);
+}
+
+// SUPERSET of "a seed hit of this diagonal starts at frame bit B + i" for i = 0 .. 31 (bit i of the result): ten of
+// the twelve care positions (0.1 % false alarms over the 96 starts of a frame; eight gave 2.9 %), no seed-validity
+// planes — a false alarm only sends the pair to the exact walk.
+// n0 / n1: the words of nm = dl | dh that hold bits B - 13 .. B + 50 (B = 13 + 32 k); d0 / d1: the same of dl.
+__device__ __forceinline__ uint32_t seed_alarm32(uint32_t n0, uint32_t n1, uint32_t d0, uint32_t d1, int transitions) {
+    uint32_t ones = 0, twos = 0, tv = 0;
+#pragma unroll
+    for (int c = 0; c < SEED_LEN; c++) {
+        if (!((CARE10 >> c) & 1u)) continue;
+        const uint32_t v = __builtin_amdgcn_alignbit(n1, n0, 13 + c);
+        twos |= ones & v;
+        ones |= v;
+        tv |= __builtin_amdgcn_alignbit(d1, d0, 13 + c);
+    }
+    return ~(transitions ? (twos | tv) : ones);
+}
+
+// true = the pair needs the exact walk.  Same three proofs as hit_needs_walk (k4_device.h) on frames in the common
+// alignment: left walk = frame bits 127 .. 32 (six blocks), right walk = bits 128 .. 191 (four blocks), seed windows
+// that end where left step s arrives start at bit 108 - s.
+__device__ __forceinline__ bool pair_needs_walk(const uint4 t0, const uint4 t1, const uint4 t2, const uint4 q0, const uint4 q1,
+                                                const uint4 q2, int xdrop, int hspthresh, int transitions, uint32_t *why = nullptr) {
+    // planes: lo = {0.x 0.y 0.z 0.w 1.x 1.y}, hi = {1.z 1.w 2.x 2.y 2.z 2.w}
+    const uint32_t dl0 = t0.x ^ q0.x, dl1 = t0.y ^ q0.y, dl2 = t0.z ^ q0.z, dl3 = t0.w ^ q0.w, dl4 = t1.x ^ q1.x, dl5 = t1.y ^ q1.y;
+    const uint32_t dh0 = t1.z ^ q1.z, dh1 = t1.w ^ q1.w, dh2 = t2.x ^ q2.x, dh3 = t2.y ^ q2.y, dh4 = t2.z ^ q2.z, dh5 = t2.w ^ q2.w;
+    const uint32_t cg1 = t0.y ^ t1.w, cg2 = t0.z ^ t2.x, cg3 = t0.w ^ t2.y, cg4 = t1.x ^ t2.z, cg5 = t1.y ^ t2.w;
+    // earlier seed hits: starts 77..108 <-> left steps 31..0, 45..76 <-> steps 63..32, 13..44 <-> steps 95..64
+    const uint32_t n0 = dl0 | dh0, n1 = dl1 | dh1, n2 = dl2 | dh2, n3 = dl3 | dh3;
+    const uint32_t h0 = seed_alarm32(n2, n3, dl2, dl3, transitions);   // bit 31 - s  <-> step s      (s = 0..31)
+    const uint32_t h1 = seed_alarm32(n1, n2, dl1, dl2, transitions);   // bit 63 - s  <-> step s      (s = 32..63)
+    const uint32_t h2 = seed_alarm32(n0, n1, dl0, dl1, transitions);   // bit 95 - s  <-> step s      (s = 64..95)
+    Bound L{0, 0, 0, 0, false}, R{0, 0, 0, 0, false};
+    uint32_t veto = 0;
+    // a boundary only counts while the walk is not yet proven to have stopped
+    veto |= h0 >> 16;                        bound_block(L, dl3 >> 16, dh3 >> 16, cg3 >> 16, xdrop);
+    veto |= L.stop ? 0u : (h0 & 0xFFFFu);    bound_block(L, dl3 & 0xFFFFu, dh3 & 0xFFFFu, cg3 & 0xFFFFu, xdrop);
+    veto |= L.stop ? 0u : (h1 >> 16);        bound_block(L, dl2 >> 16, dh2 >> 16, cg2 >> 16, xdrop);
+    veto |= L.stop ? 0u : (h1 & 0xFFFFu);    bound_block(L, dl2 & 0xFFFFu, dh2 & 0xFFFFu, cg2 & 0xFFFFu, xdrop);
+    veto |= L.stop ? 0u : (h2 >> 16);        bound_block(L, dl1 >> 16, dh1 >> 16, cg1 >> 16, xdrop);
+    veto |= L.stop ? 0u : (h2 & 0xFFFFu);    bound_block(L, dl1 & 0xFFFFu, dh1 & 0xFFFFu, cg1 & 0xFFFFu, xdrop);
+    bound_block(R, dl4 & 0xFFFFu, dh4 & 0xFFFFu, cg4 & 0xFFFFu, xdrop);
+    bound_block(R, dl4 >> 16, dh4 >> 16, cg4 >> 16, xdrop);
+    bound_block(R, dl5 & 0xFFFFu, dh5 & 0xFFFFu, cg5 & 0xFFFFu, xdrop);
+    bound_block(R, dl5 >> 16, dh5 >> 16, cg5 >> 16, xdrop);
+    if (why) *why = (L.stop ? 0u : 1u) | (R.stop ? 0u : 2u) | (L.ub + R.ub < hspthresh ? 0u : 4u) | (veto ? 8u : 0u);
+    return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
+}
+
+__device__ __forceinline__ uint4 bperm4(uint32_t src_lane, const uint4 v) {
+    const int a = (int)(src_lane << 2);
+    return make_uint4((uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.x), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.y),
+                      (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.z), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.w));
+}
+
+template <int THREADS, uint32_t QSEG>
+struct FusedCfg {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr size_t SMEM = (TILE_WORDS + 4) * 4 + (size_t)QSEG * 48 + (size_t)WAVES * DQ * 4 + (size_t)WAVES * 64 * 8 + QSEG + 16;
+};
+
+template <int THREADS, uint32_t QSEG>
+__global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
+    constexpr int WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *sQ = reinterpret_cast<uint32_t *>(smem);                                  // TILE_WORDS + 4
+    uint4 *sQF = reinterpret_cast<uint4 *>(smem + (TILE_WORDS + 4) * 4);                 // 3 parts of QSEG
+    uint32_t *sD_all = reinterpret_cast<uint32_t *>(sQF + QSEG * 3);                     // WAVES * DQ
+    uint2 *s_walk_all = reinterpret_cast<uint2 *>(sD_all + WAVES * DQ);                  // WAVES * 64
+    uint8_t *sQN = reinterpret_cast<uint8_t *>(s_walk_all + WAVES * 64);                 // QSEG
+    unsigned long long *s_total = reinterpret_cast<unsigned long long *>(sQN + QSEG);
+
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t t0 = A.T.off[(size_t)tile * TILE_WORDS], nT = A.T.off[(size_t)tile * TILE_WORDS + TILE_WORDS] - t0;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.Q.off + (size_t)tile * TILE_WORDS);
+        uint4 *dst = reinterpret_cast<uint4 *>(sQ);
+        for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += THREADS) dst[k] = src[k];
+        if (threadIdx.x == 0) { sQ[TILE_WORDS] = A.Q.off[(size_t)tile * TILE_WORDS + TILE_WORDS]; *s_total = 0ull; }
+    }
+    __syncthreads();
+    const uint32_t q0 = sQ[0], nQ = sQ[TILE_WORDS] - q0;
+    if (!nT || !nQ) {
+        if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
+        return;
+    }
+    uint32_t *sD = sD_all + wv * DQ;
+    uint2 *s_walk = s_walk_all + wv * 64;
+    uint32_t n_walk = 0;
+    unsigned long long wave_hits = 0;
+    const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
+
+    // the walk queue takes the staged survivors 64 at a time (one atomic per flush)
+    auto flush_walk = [&](uint32_t n) {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&A.q.ctr->nwalk, (unsigned long long)n);
+        b = __shfl(b, 0);
+        if (lane < n && b + lane < A.q.walk_cap) { A.q.walkq[b + lane] = s_walk[lane]; A.q.walku[b + lane] = A.unit; }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    const uint32_t nchunks = (nT + TCH - 1) / TCH;
+    // my first chunk's frames (one entry per lane): in flight while the first query segment is staged
+    uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = nf0, nf2 = nf0;
+    uint32_t npos = 0;
+    if (wv < nchunks) {
+        const uint32_t e = wv * TCH + lane;
+        if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+    }
+    for (uint32_t qs = 0; qs < nQ; qs += QSEG) {
+        const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
+        __syncthreads();  // every wavefront is through with the previous segment
+        {
+            const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
+            for (uint32_t i = threadIdx.x; i < qn; i += THREADS) {
+                sQF[i] = s0[i];
+                sQF[QSEG + i] = s1[i];
+                sQF[2 * QSEG + i] = s2[i];
+                sQN[i] = (uint8_t)(A.Q.pos[q0 + qs + i] >> 31);
+            }
+        }
+        __syncthreads();
+        for (uint32_t ch = wv; ch < nchunks; ch += WAVES) {
+            const uint32_t e0 = ch * TCH, ne = min(TCH, nT - e0);
+            const uint4 f0 = nf0, f1 = nf1, f2 = nf2;
+            const uint32_t mypos = npos;
+            {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
+                uint32_t nx = ch + WAVES;
+                if (nx >= nchunks) nx = (qs + QSEG < nQ) ? wv : 0xFFFFFFFFu;
+                if (nx != 0xFFFFFFFFu && nx != ch) {
+                    const uint32_t e = nx * TCH + lane;
+                    if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+                }
+            }
+            const bool tvalid = lane < ne;
+            const uint32_t tflag = tvalid ? (mypos >> 31) : 0u;
+            // my entry's in-tile key from its own frame: hi plane, seed window = frame bits 109 .. 127 (hi3 = f2.y)
+            uint32_t w = 0, c = 0, nmask = 0;
+            if (tvalid) {
+                w = pext12(f2.y >> 13);
+                const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
+                for (int j = 0; j < nn; j++) {
+                    const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                    const uint32_t a = max(sQ[w2] - q0, qs), b = min(sQ[w2 + 1] - q0, qe);
+                    if (a < b) { c += b - a; nmask |= 1u << j; }
+                }
+            }
+            uint32_t inc = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(inc, o);
+                if (lane >= (uint32_t)o) inc += v;
+            }
+            const uint32_t tot = __shfl(inc, 63), st = inc - c;
+            wave_hits += tot;
+            for (uint32_t rb = 0; rb < tot; rb += DQ) {
+                if (c && st < rb + DQ && st + c > rb) {
+                    uint32_t acc = st;
+                    for (uint32_t m = nmask; m; m &= m - 1u) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(m);
+                        const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
+                        const uint32_t a = max(sQ[w2] - q0, qs), b = min(sQ[w2 + 1] - q0, qe);
+                        const uint32_t g0 = max(acc, rb), g1 = min(acc + (b - a), rb + DQ);
+                        for (uint32_t g = g0; g < g1; g++) sD[g - rb] = (lane << 16) | (a + (g - acc) - qs);
+                        acc += b - a;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t n = min(DQ, tot - rb);
+                for (uint32_t i = 0; i < n; i += 64) {
+                    const bool valid = i + lane < n;
+                    const uint32_t d = valid ? sD[i + lane] : 0u;
+                    const uint32_t owner = d >> 16, qi = d & 0xFFFFu;
+                    // the target frame lives in its owner lane's registers, the query frame in LDS
+                    const uint4 ta = bperm4(owner, f0), tb = bperm4(owner, f1), tc = bperm4(owner, f2);
+                    const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
+                    const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
+                    bool need = false;
+                    if (valid) {
+                        if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
+                        else need = ((tpf >> 31) | sQN[qi]) != 0 ||
+                                    pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
+#ifdef MIMEO_K34_WHY
+                        if ((A.dbg & 8u) && need) {
+                            uint32_t why = 0;
+                            pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions, &why);
+                            if (why & 1u) atomicAdd(&A.q.ctr->dbg[0], 1ull);
+                            if (why & 2u) atomicAdd(&A.q.ctr->dbg[1], 1ull);
+                            if (why & 4u) atomicAdd(&A.q.ctr->dbg[2], 1ull);
+                            if (why & 8u) atomicAdd(&A.q.ctr->dbg[3], 1ull);
+                            if (why == 8u) atomicAdd(&A.q.ctr->dbg[4], 1ull);
+                            if (why == 1u) atomicAdd(&A.q.ctr->dbg[5], 1ull);
+                            if (why == 2u) atomicAdd(&A.q.ctr->dbg[6], 1ull);
+                            if (why == 4u) atomicAdd(&A.q.ctr->dbg[7], 1ull);
+                        }
+#endif
+                        if (A.dbg & 2u) need = false;
+                    }
+                    const uint32_t tp = tpf & POS_MASK;
+                    uint32_t qp = 0;
+                    if (A.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
+                        if (valid) {
+                            qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                            if (tp == qp) need = false;
+                        }
+                    } else if (need) {
+                        qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                    }
+                    const uint64_t m = __ballot(need);
+                    if (m) {
+                        const uint32_t add = (uint32_t)__popcll(m);
+                        if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
+                        if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tp, qp);
+                        n_walk += add;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            (void)tflag;
+        }
+    }
+    if (n_walk) flush_walk(n_walk);
+    if (lane == 0) atomicAdd(s_total, wave_hits);
+    __syncthreads();
+    if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = *s_total;
+}
+
+// one workgroup per unit: unit_hits[u] = sum of its tile counts (once per batch)
+__global__ __launch_bounds__(256) void k34_sum_hits(const unsigned long long *__restrict__ tile_hits, unsigned long long *__restrict__ unit_hits) {
+    __shared__ unsigned long long red[256];
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < NTILE; i += 256) s += tile_hits[(size_t)blockIdx.x * NTILE + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) unit_hits[blockIdx.x] = red[0];
+}
+void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st) {
+    hipLaunchKernelGGL(k34_sum_hits, dim3(nunits), dim3(256), 0, st, (const unsigned long long *)q.tile_hits, q.unit_hits);
+}
+
+template <int THREADS, uint32_t QSEG>
+static int launch_cfg(const FusedArgs &A, hipStream_t st) {
+    static bool attr_done = false;
+    constexpr size_t smem = FusedCfg<THREADS, QSEG>::SMEM;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<THREADS, QSEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k34_scan_extend<THREADS, QSEG>), dim3(NTILE), dim3(THREADS), smem, st, A);
+    return 0;
+}
+
+int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
+                      hipStream_t st) {
+    (void)tab;
+    FusedArgs A;
+    A.T = w.ti; A.Q = w.qi; A.q = q;
+    A.unit = unit; A.same = w.d.same;
+    A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
+    A.dbg = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
+    // workgroup shape: one 1024-thread workgroup per CU with a 2048-entry query segment (most 10 Mbp x 10 Mbp tiles in
+    // two passes), or two 512-thread workgroups per CU with 1024-entry segments (scaffolds up to ~5 Mbp: one pass)
+    static const int cfg = getenv("MIMEO_K34_CFG") ? atoi(getenv("MIMEO_K34_CFG")) : 0;
+    const uint32_t avg = (uint32_t)(((uint64_t)w.qi.n + NTILE - 1) / NTILE);
+    const bool big = cfg ? cfg == 1 : avg > 900;
+    return big ? launch_cfg<1024, 2048>(A, st) : launch_cfg<512, 1024>(A, st);
+}
+
+}  // namespace mimeo

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
     const uint32_t q0t = sQ[0], nQ = sQ[TILE_WORDS] - q0t;
     const bool qcached = nQ <= qcache_n;
     if (qcached) {
-        for (uint32_t i = threadIdx.x; i < nQ; i += FILL_THREADS) sPQ[i] = posQ[q0t + i];
+        for (uint32_t i = threadIdx.x; i < nQ; i += FILL_THREADS) sPQ[i] = posQ[q0t + i] & POS_MASK;
         __syncthreads();
     }
     uint32_t par = 0;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
             total += v;
         }
         if (c) {
-            const uint32_t tp = posT[g];
+            const uint32_t tp = posT[g] & POS_MASK;  // bit 31 flags a frame with an N (K34)
             uint2 *dst = hits + out + (wbase + inc - c);
             // only the non-empty neighbours (3-4 of the 13 on random sequence), in the same order as before
             for (uint32_t m = nmask; m; m &= m - 1u) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
                 if (qcached)
                     for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, sPQ[b - q0t]);
                 else
-                    for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, posQ[b]);
+                    for (uint32_t b = q0; b < q1; b++) *dst++ = make_uint2(tp, posQ[b] & POS_MASK);
             }
         }
         out += total;
@@ -218,8 +218,9 @@ void JoinCtx::release() {
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
 }
 
+// exact mode only (stage entry point mimeo_seed_hits and the A/B heavy path): one host round trip for the hit count
 int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transitions, DeviceBuf &hits, uint64_t *nhits,
-              JoinTiming *tm, Exclusive *ex, uint64_t spec_cap, uint64_t max_hits) {
+              JoinTiming *tm) {
     if (!ctx.tile_count) {
         HIP_TRY(hipMalloc((void **)&ctx.tile_count, (NTILE + 2) * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&ctx.tile_base, (NTILE + 2) * sizeof(unsigned long long)));
@@ -227,79 +228,40 @@ int join_hits(JoinCtx &ctx, const IndexView &T, const IndexView &Q, int transiti
     if (!ctx.ev[0])
         for (auto &e : ctx.ev) HIP_TRY(hipEventCreate(&e));
     hipStream_t st = stream();
-    // timing of the previous speculative launch on this context is collected now (its events have long fired)
-    if (ctx.pending_tm) {
-        float a = 0, b = 0;
-        if (hipEventSynchronize(ctx.ev[3]) == hipSuccess && hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]) == hipSuccess &&
-            hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]) == hipSuccess) {
-            ctx.pending_tm->ms_count += a;
-            ctx.pending_tm->ms_fill += b;
-        }
-        ctx.pending_tm = nullptr;
-    }
     HIP_TRY(hipEventRecord(ctx.ev[0], st));
     hipLaunchKernelGGL(k3_join_count, dim3(NTILE), dim3(JOIN_THREADS), 0, st, T.off, Q.off, transitions, ctx.tile_count);
     hipLaunchKernelGGL(k3_tile_scan, dim3(1), dim3(1024), 0, st, ctx.tile_count, ctx.tile_base);
     HIP_TRY(hipEventRecord(ctx.ev[1], st));
-    unsigned long long total = 0, cap = ~0ull;
-    if (spec_cap) {
-        // no round trip: the fill (and K4 behind it) read the hit count from device memory; a count beyond
-        // the buffer makes them do nothing and the caller repeats the unit with the exact size
-        cap = spec_cap;
-        int rc = hits.reserve((size_t)spec_cap * sizeof(uint2));
-        if (rc) return rc;
-        *nhits = 0;
-    } else {
-        HIP_TRY(hipMemcpyAsync(&total, ctx.tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        *nhits = total;
-        if (total > max_hits) return MIMEO_SPLIT;
-        if (total >= (1ull << 32)) {
-            set_error("one (target, query, strand) unit yields 2^32 or more seed hits (low-complexity sequence?): not supported");
-            return MIMEO_ERR_LIMIT;
-        }
-        int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
-        if (rc) return rc;
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, ctx.tile_base + NTILE, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *nhits = total;
+    if (total >= (1ull << 32)) {
+        set_error("one (target, query, strand) unit yields 2^32 or more seed hits: the stand-alone seed scan cannot hold them (the fused path has no such limit)");
+        return MIMEO_ERR_LIMIT;
     }
-    if (ex) ex->begin(st);
-    hipError_t e2 = hipEventRecord(ctx.ev[2], st);
+    int rc = hits.reserve((size_t)(total ? total : 1) * sizeof(uint2));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx.ev[2], st));
     {
         // the small cache when the average tile's query slice fits it with room to spare (tiles beyond it read
         // the positions from L2 instead): 4 instead of 3 workgroups per CU, 0.157 -> 0.145 ms on a C2 unit
         const uint32_t qn = ((uint64_t)Q.n * 3 / 2) / NTILE <= FILL_QCACHE_SMALL ? FILL_QCACHE_SMALL : FILL_QCACHE;
-        if (spec_cap || total)
+        if (total)
             hipLaunchKernelGGL(k3_join_fill, dim3(NTILE), dim3(FILL_THREADS), qn * sizeof(uint32_t), st, T.off, T.pos, Q.off, Q.pos,
-                               transitions, ctx.tile_base, (uint2 *)hits.p, cap, qn);
+                               transitions, ctx.tile_base, (uint2 *)hits.p, ~0ull, qn);
     }
-    hipError_t e3 = hipEventRecord(ctx.ev[3], st);
-    if (ex) ex->end(st);
-    HIP_TRY(e2);
-    HIP_TRY(e3);
+    HIP_TRY(hipEventRecord(ctx.ev[3], st));
     HIP_TRY(hipGetLastError());
     if (tm) {
-        if (spec_cap) {
-            ctx.pending_tm = tm;  // read at the next call on this context, or by join_timing_flush
-        } else {
-            HIP_TRY(hipEventSynchronize(ctx.ev[3]));
-            float a = 0, b = 0;
-            HIP_TRY(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
-            HIP_TRY(hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]));
-            tm->ms_count += a;
-            tm->ms_fill += b;
-        }
+        HIP_TRY(hipEventSynchronize(ctx.ev[3]));
+        float a = 0, b2 = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b2, ctx.ev[2], ctx.ev[3]));
+        tm->ms_count += a;
+        tm->ms_fill += b2;
     }
     return 0;
-}
-
-void join_timing_flush(JoinCtx &ctx) {
-    if (!ctx.pending_tm) return;
-    float a = 0, b = 0;
-    if (hipEventSynchronize(ctx.ev[3]) == hipSuccess && hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]) == hipSuccess &&
-        hipEventElapsedTime(&b, ctx.ev[2], ctx.ev[3]) == hipSuccess) {
-        ctx.pending_tm->ms_count += a;
-        ctx.pending_tm->ms_fill += b;
-    }
-    ctx.pending_tm = nullptr;
 }
 
 }  // namespace mimeo

@@ -35,23 +35,29 @@ __device__ __forceinline__ bool anchor_less(const mimeo_hsp &a, const mimeo_hsp 
     return hsp_less(a, b);
 }
 
-// sort plumbing: key1 = (qstart, length), key2 = (start of the group's range, tstart)
-__global__ void k5_group_begin(const Group *__restrict__ groups, uint32_t *__restrict__ gb) {
-    const Group &G = groups[blockIdx.x];
-    for (uint64_t i = G.hsp_begin + threadIdx.x; i < G.hsp_end; i += blockDim.x) gb[i] = (uint32_t)G.hsp_begin;
-}
+// sort plumbing: key1 = (qstart, length), key2 = (group = unit of the batch, tstart); the HSPs arrive in no order,
+// tagged with their unit (K4 works on the whole batch at once)
 __global__ void k5_key1(const mimeo_hsp *__restrict__ in, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     key[i] = ((uint64_t)in[i].qstart << 32) | in[i].length;
     val[i] = (uint32_t)i;
 }
-__global__ void k5_key2(const mimeo_hsp *__restrict__ in, const uint32_t *__restrict__ gb, const uint32_t *__restrict__ perm,
+__global__ void k5_key2(const mimeo_hsp *__restrict__ in, const uint32_t *__restrict__ unit, const uint32_t *__restrict__ perm,
                         uint64_t n, uint64_t *__restrict__ key) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = perm[i];
-    key[i] = ((uint64_t)gb[src] << 32) | in[src].tstart;
+    key[i] = ((uint64_t)unit[src] << 32) | in[src].tstart;
+}
+// the sorted keys carry the group in their high word: a group's HSP range is where that word changes (groups
+// without HSPs keep the empty range the host gave them)
+__global__ void k5_group_ranges(const uint64_t *__restrict__ key, uint64_t n, Group *__restrict__ groups) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = (uint32_t)(key[i] >> 32);
+    if (i == 0 || (uint32_t)(key[i - 1] >> 32) != g) groups[g].hsp_begin = i;
+    if (i + 1 == n || (uint32_t)(key[i + 1] >> 32) != g) groups[g].hsp_end = i + 1;
 }
 __global__ void k5_gather(const mimeo_hsp *__restrict__ in, const uint32_t *__restrict__ perm, uint64_t n,
                           mimeo_hsp *__restrict__ hs) {
@@ -198,18 +204,17 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
     if (tid == 0) G.nchain = s_m;
 }
 
-int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uint64_t nhsps, int do_chain,
-                 mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order) {
+int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
+                 int do_chain, mimeo_hsp *d_sorted, long long *d_best, long long *d_cand, int *d_pred, uint32_t *d_order) {
     if (!ngroups || !nhsps) return 0;
     if (nhsps >= (1ull << 32)) { set_error("more than 2^32 HSPs in one batch"); return MIMEO_ERR_LIMIT; }
     hipStream_t st = stream();
-    static DeviceBuf kA, kB, vA, vB, gb, tmp;  // K5 runs on the calling thread only
+    static DeviceBuf kA, kB, vA, vB, tmp;  // K5 runs on the calling thread only
     int rc;
     if ((rc = kA.reserve(nhsps * 8)) || (rc = kB.reserve(nhsps * 8)) || (rc = vA.reserve(nhsps * 4)) ||
-        (rc = vB.reserve(nhsps * 4)) || (rc = gb.reserve(nhsps * 4)))
+        (rc = vB.reserve(nhsps * 4)))
         return rc;
     const dim3 blk(256), grd((uint32_t)((nhsps + 255) / 256));
-    hipLaunchKernelGGL(k5_group_begin, dim3(ngroups), blk, 0, st, (const Group *)d_groups, (uint32_t *)gb.p);
     hipLaunchKernelGGL(k5_key1, grd, blk, 0, st, d_hsps, nhsps, (uint64_t *)kA.p, (uint32_t *)vA.p);
     size_t tb = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vA.p, (uint32_t *)vB.p,
@@ -217,9 +222,10 @@ int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, uin
     if ((rc = tmp.reserve(tb + 16))) return rc;
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vA.p, (uint32_t *)vB.p,
                                       (size_t)nhsps, 0, 64, st));
-    hipLaunchKernelGGL(k5_key2, grd, blk, 0, st, d_hsps, (const uint32_t *)gb.p, (const uint32_t *)vB.p, nhsps, (uint64_t *)kA.p);
+    hipLaunchKernelGGL(k5_key2, grd, blk, 0, st, d_hsps, d_hsp_unit, (const uint32_t *)vB.p, nhsps, (uint64_t *)kA.p);
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vB.p, (uint32_t *)vA.p,
                                       (size_t)nhsps, 0, 64, st));
+    hipLaunchKernelGGL(k5_group_ranges, grd, blk, 0, st, (const uint64_t *)kB.p, nhsps, d_groups);
     hipLaunchKernelGGL(k5_gather, grd, blk, 0, st, d_hsps, (const uint32_t *)vA.p, nhsps, d_sorted);
     hipLaunchKernelGGL(k5_chain, dim3(ngroups), dim3(CH_THREADS), 0, st, d_groups, d_sorted, d_best,
                        d_cand, d_pred, d_order, do_chain);

@@ -11,7 +11,7 @@ g = engine.Genome(names, seqs)
 t = time.time()
 a = engine.align_pair(g, 0, g, 0)
 st = engine.stats()
-print('L', L, 'alns', a.size, 'wall %.2f s' % (time.time() - t), 'lanes', st['lanes'], 'hits %.3g' % st['seed_hits'], 'hsps', st['hsps'], flush=True)
+print('L', L, 'alns', a.size, 'wall %.2f s' % (time.time() - t), 'hits %.3g' % st['seed_hits'], 'hsps', st['hsps'], flush=True)
 triv = a[(a['tstart'] == 0) & (a['tend'] == L) & (a['qstrand'] == 0)]
 print('trivial', triv.size, int(triv['score'][0]) if triv.size else None)
 g.close()

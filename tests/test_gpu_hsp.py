@@ -139,48 +139,41 @@ def test_parameter_domain_is_enforced(eng):
     g.close()
 
 
-def test_prefilter_variants_give_identical_hsps(tmp_path):
-    """The K4 pre-filter (popcount prefix bounds; variants 9 = two-plane copy, 5 = full planes, 4 = finer
-    checkpoints) may only drop hits that the exact walk (variant 1: every hit walked) would drop too:
-    the HSP sets must be byte-identical, on N-free sequence (9 is the default there) and with N runs."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, hashlib, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from mimeo_amd import engine\n"
-        "from mimeo_amd.synth import synth_genome\n"
-        "engine.init(0)\n"
-        "names, seqs = synth_genome(91, 1_200_000, 2, repeat_frac=0.15, families=5, cons_len=(200, 3000), max_div=0.2)\n"
-        "seqs = [s.copy() for s in seqs]\n"
-        "if sys.argv[1] == 'n':\n"
-        "    seqs[0][5000:5300] = ord('N'); seqs[1][70000:70010] = ord('N')\n"
-        "g = engine.Genome(names, seqs)\n"
-        "out = []\n"
-        "for t, q in ((0, 1), (0, 0)):\n"
-        "    for strand in (0, 1):\n"
-        "        h = engine.ungapped_hsps(g, t, g, q, strand)\n"
-        "        out.append(h.tobytes())\n"
-        "print(hashlib.sha1(b''.join(out)).hexdigest(), sum(len(o) for o in out) // 32)\n" % root)
-    script = tmp_path / 'v.py'
-    script.write_text(code)
+def test_heavy_kernel_variants_give_identical_hsps(eng, monkeypatch):
+    """Two independent decompositions of the stage must give byte-identical HSP sets: the fused seed-scan /
+    pre-filter / walk kernel on seed frames (K34, production) and the round-1 pair "materialised hit array +
+    K4 fast kernel" (MIMEO_HEAVY=v1) with its pre-filter on the two-plane copy (9), on the full planes (5) and
+    without any pre-filter (1: every hit walked exactly).  A pre-filter may only drop hits whose exact walk
+    yields nothing.  On N-free sequence and with N runs, cross and self units, both strands; and with the
+    queues so small that the batch is repeated (MIMEO_QUEUE_SHRINK)."""
+    names, seqs = synth_genome(91, 1_200_000, 2, repeat_frac=0.15, families=5, cons_len=(200, 3000), max_div=0.2)
     for mode in ('clean', 'n'):
+        ss = [s.copy() for s in seqs]
+        if mode == 'n':
+            ss[0][5000:5300] = ord('N'); ss[1][70000:70010] = ord('N'); ss[1][300000:300001] = ord('N')
+        g = eng.Genome(names, ss)
         res = {}
-        for v in ('1', '4', '5', '9', ''):
-            if mode == 'n' and v == '9':
-                continue  # the two-plane copy carries no N plane: the host never selects 9 for such strands
-            env = dict(os.environ)
-            env.pop('MIMEO_K4_VARIANT', None)
-            if v:
-                env['MIMEO_K4_VARIANT'] = v
-            r = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=600, env=env)
-            assert r.returncode == 0, r.stderr[-2000:]
-            res[v or 'default'] = r.stdout.strip().split('\n')[-1]
-        assert len(set(res.values())) == 1, (mode, res)
-        assert int(res['1'].split()[1]) > 100
+        for tag, env in (('fused', {}), ('v1', {'MIMEO_HEAVY': 'v1'}), ('v1_walk_all', {'MIMEO_HEAVY': 'v1', 'MIMEO_K4_VARIANT': '1'}),
+                         ('v1_full_planes', {'MIMEO_HEAVY': 'v1', 'MIMEO_K4_VARIANT': '5'}), ('fused_rerun', {'MIMEO_QUEUE_SHRINK': '4000'})):
+            for k in ('MIMEO_HEAVY', 'MIMEO_K4_VARIANT', 'MIMEO_QUEUE_SHRINK'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out, hits, reruns = [], 0, 0
+            for t, q in ((0, 1), (0, 0)):
+                for strand in (0, 1):
+                    out.append(eng.ungapped_hsps(g, t, g, q, strand))
+                    st = eng.stats()
+                    hits += st['seed_hits']
+                    reruns += st['queue_reruns']
+            res[tag] = (b''.join(o.tobytes() for o in out), hits)
+            assert (reruns > 0) == (tag == 'fused_rerun'), (tag, reruns)
+        for k in ('MIMEO_HEAVY', 'MIMEO_K4_VARIANT', 'MIMEO_QUEUE_SHRINK'):
+            monkeypatch.delenv(k, raising=False)
+        assert len(res['fused'][0]) // 32 > 100
+        for tag in res:
+            assert res[tag] == res['fused'], (mode, tag, len(res[tag][0]) // 32, res[tag][1], res['fused'][1])
+        g.close()
 
 
 def test_tiny_scaffolds_and_hits_at_the_ends(eng):

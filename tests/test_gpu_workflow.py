@@ -222,30 +222,40 @@ def test_lastz_shim_runs_the_reference_invocation(eng, tmp_path):
     assert bad.returncode != 0
 
 
-def test_pipeline_modes_give_identical_alignments(tmp_path):
-    """The scheduling options of the unit pipeline must not change a single record: one lane vs two,
-    speculative buffers vs exact, and speculative buffers that are too small (every unit is then repeated
-    with the exact size: MIMEO_SPEC_SHRINK forces that path)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
-            "from mimeo_amd import engine\n"
-            "from mimeo_amd.synth import synth_genome\n"
-            "engine.init(0)\n"
-            "n, s = synth_genome(77, 1_500_000, 3, repeat_frac=0.08, families=6, cons_len=(300, 2500))\n"
-            "g = engine.Genome(n, s)\n"
-            "a = engine.align_pairs(g, None, [(t, q) for t in range(3) for q in range(3)])\n"
-            "print(a.size, hashlib.md5(a.tobytes()).hexdigest(), engine.stats()['seed_hits'])\n") % root
+def test_pipeline_modes_give_identical_alignments(eng, monkeypatch):
+    """How a call is cut into batches must not change a single record: one batch for everything, one unit per
+    batch, five units per batch, batches cut by expected seed hits, queues so small that every batch is repeated
+    with larger ones, and the round-1 heavy kernels in the place of the fused one."""
+    import hashlib
+    n, s = synth_genome(77, 1_500_000, 3, repeat_frac=0.08, families=6, cons_len=(300, 2500))
+    g = eng.Genome(n, s)
+    pairs = [(t, q) for t in range(3) for q in range(3)]
     outs = {}
-    for tag, env in (('default', {}), ('one_lane', {'MIMEO_LANES': '1'}), ('exact', {'MIMEO_NO_SPEC': '1'}),
-                     ('no_handover', {'MIMEO_NO_HANDOVER': '1'}), ('retry', {'MIMEO_SPEC_SHRINK': '1000'}),
-                     ('three_lanes', {'MIMEO_LANES': '3'})):
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-        assert r.returncode == 0, (tag, r.stderr[-2000:])
-        outs[tag] = r.stdout.strip().split('\n')[-1]
+    knobs = ('MIMEO_BATCH_UNITS', 'MIMEO_BATCH_HITS', 'MIMEO_QUEUE_SHRINK', 'MIMEO_HEAVY')
+    for tag, env in (('default', {}), ('one_unit', {'MIMEO_BATCH_UNITS': '1'}), ('five_units', {'MIMEO_BATCH_UNITS': '5'}),
+                     ('by_hits', {'MIMEO_BATCH_HITS': '6e5'}), ('rerun', {'MIMEO_QUEUE_SHRINK': '3000'}), ('v1', {'MIMEO_HEAVY': 'v1'})):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = eng.align_pairs(g, None, pairs)
+        st = eng.stats()
+        outs[tag] = (a.size, hashlib.md5(a.tobytes()).hexdigest(), st['seed_hits'], st['hsps'])
+        if tag == 'default':
+            assert st['batches'] == 1 and st['queue_reruns'] == 0 and st['pair_strands'] == 18
+        if tag == 'one_unit':
+            assert st['batches'] == 18
+        if tag == 'five_units':
+            assert st['batches'] == 4
+        if tag == 'by_hits':
+            assert 2 < st['batches'] < 18
+        if tag == 'rerun':
+            assert st['queue_reruns'] >= 1
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
     assert len(set(outs.values())) == 1, outs
-    assert int(outs['default'].split()[0]) > 10
+    assert outs['default'][0] > 10
+    g.close()
 
 
 def test_kept_seed_indexes_are_reused_and_change_nothing(eng):
@@ -285,7 +295,7 @@ def test_kept_seed_indexes_are_reused_and_change_nothing(eng):
 
 
 def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
-    """A genome of many scaffolds cannot keep every seed index (64 MiB + 4 B/base per strand) on the device: the
+    """A genome of many scaffolds cannot keep every seed index (64 MiB + 52 B/base per strand) on the device: the
     pair matrix is then cut into blocks whose indexes fit, rebuilt block by block.  Same records as one block."""
     from mimeo_amd import workflow
     names, seqs = synth_genome(123, 600_000, 6, repeat_frac=0.25, families=3, cons_len=(300, 1500), max_div=0.1)
@@ -298,10 +308,6 @@ def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
     st = eng.stats()
     assert st['index_blocks'] >= 9, st['index_blocks']
     assert blocked.tobytes() == whole.tobytes()
-    assert st['lanes'] == 3
-    monkeypatch.setenv('MIMEO_LANE_BUDGET_MB', '200')      # the lanes' buffers of large scaffolds would not fit: one lane
-    assert eng.align_pairs(A, None, pairs).tobytes() == whole.tobytes() and eng.stats()['lanes'] == 1
-    monkeypatch.delenv('MIMEO_LANE_BUDGET_MB')
     sub = [(5, 0), (0, 5), (2, 2), (3, 1)]                # an arbitrary pair list, not a full matrix
     monkeypatch.delenv('MIMEO_INDEX_BUDGET_MB')
     ref = eng.align_pairs(A, None, sub)
@@ -310,31 +316,18 @@ def test_index_blocks_when_the_seed_indexes_do_not_fit(eng, monkeypatch):
     A.close()
 
 
-def test_chunked_units_give_the_same_alignments(eng, monkeypatch):
-    """A unit beyond MIMEO_CHUNK_HITS expected seed hits (default 1.5e9: scaffolds of ~45 Mbp and more) is joined
-    chunk by chunk of the query, followers and candidates resolved once at the end.  Forced here on small
-    scaffolds with long repeat copies (follower chains cross the chunk borders): byte-identical records,
-    and equal to the oracle."""
+def test_long_repeat_copies_match_the_oracle(eng):
+    """Long repeat copies (2-9 kbp, 5 % divergence: follower chains of hundreds of seed hits per diagonal, walks far
+    beyond the frame) through the whole pipeline against the oracle, pair by pair."""
     from oracle import oracle as O
-    for var in ('MIMEO_CHUNK_HITS', 'MIMEO_CHUNK_MAX_HITS'):  # a sweep that exported them must not leak into the baseline run
-        monkeypatch.delenv(var, raising=False)
     names, seqs = synth_genome(321, 900_000, 3, repeat_frac=0.3, families=3, cons_len=(2000, 9000), max_div=0.05)
     A = eng.Genome(names, seqs)
     pairs = [(0, 1), (1, 1), (2, 0)]
     whole = eng.align_pairs(A, None, pairs)
-    assert eng.stats()['chunked_units'] == 0 and whole.size > 20
-    for limit in ('2e4', '3e3'):       # ~ 6 and ~ 35 chunks per unit
-        monkeypatch.setenv('MIMEO_CHUNK_HITS', limit)
-        got = eng.align_pairs(A, None, pairs)
-        assert eng.stats()['chunked_units'] == 6
-        assert got.tobytes() == whole.tobytes(), limit
-    monkeypatch.setenv('MIMEO_CHUNK_MAX_HITS', '2000')   # chunks whose real hit count is beyond the budget are halved
-    got = eng.align_pairs(A, None, pairs)
-    assert eng.stats()['chunk_splits'] > 10 and got.tobytes() == whole.tobytes()
-    monkeypatch.delenv('MIMEO_CHUNK_MAX_HITS')
-    monkeypatch.delenv('MIMEO_CHUNK_HITS')
+    assert whole.size > 20
     cols = ['tstart', 'tend', 'qstart', 'qend', 'score', 'id_n', 'id_d', 'qstrand']
-    exp = O.align_pair(seqs[0].tobytes(), seqs[1].tobytes())
-    sub = whole[(whole['tid'] == 0) & (whole['qid'] == 1)]
-    assert np.array_equal(np.sort(sub[cols], order=cols), np.sort(exp[cols], order=cols))
+    for t, q in pairs:
+        exp = O.align_pair(seqs[t].tobytes(), seqs[q].tobytes())
+        sub = whole[(whole['tid'] == t) & (whole['qid'] == q)]
+        assert np.array_equal(np.sort(sub[cols], order=cols), np.sort(exp[cols], order=cols)), (t, q)
     A.close()

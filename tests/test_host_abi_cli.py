@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     assert declared == set(_ffi.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.mimeo_abi_version() == 1
+    assert lib.mimeo_abi_version() == _ffi.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header():
