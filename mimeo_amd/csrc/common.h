@@ -173,7 +173,7 @@ struct UnitWork {  // host side: a unit with the seed indexes its heavy kernel r
     IndexView ti, qi;
 };
 struct ExtStats {
-    uint64_t seed_hits = 0, walked = 0, followers = 0, candidates = 0, reruns = 0;
+    uint64_t seed_hits = 0, walked = 0, walk_queue = 0, followers = 0, candidates = 0, reruns = 0;
     uint64_t scan_bytes_algorithmic = 0, scan_bytes_kernel = 0, heavy_launches = 0;
     float ms_heavy = 0, ms_walk = 0, ms_tails = 0;  // ms_walk: the exact walks of the walk queue (part of ms_tails)
 };
@@ -182,8 +182,8 @@ struct ExtStats {
 // per batch: walks beyond the frame, k4_diag0 of the self units, ONE radix sort of the followers of all units,
 // segment resolution, entropy.  Two host synchronisations per batch.  Leaves nhsp HSPs in hsps / hsp_unit (device).
 struct ExtBatch {
-    DeviceBuf units, ctr, cand, fkey, fkey2, fprev, fprev2, medq, medu, longq, longu, walkq, walku, flags, segs, tmp, nsel, bigseg, hsps,
-        hsp_unit, unit_hits, tile_hits, selfs, hits;
+    DeviceBuf units, ctr, cand, fkey, fkey2, fprev, fprev2, medq, medu, longq, longu, walkq, flags, segs, tmp, nsel, bigseg, hsps,
+        hsp_unit, unit_hits, tile_hits, selfs, hits, bigcand, bigacc;
     JoinCtx jc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;      // k4_diag0 of the self units runs beside the heavy kernels

@@ -33,68 +33,80 @@ constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CAR
 struct FusedArgs {
     IndexView T, Q;
     ExtQueues q;
+    const uint32_t *tab;   // 4-base group table of the exact walk (global: 16 KiB, L1-resident)
+    uint32_t tlen, qlen;
     uint32_t unit, same;
+    uint32_t tsoft;        // the target has a seed-validity plane of its own (soft-masked bases): no frame walks
     int xdrop, hspthresh, transitions;
-    uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on, 8 = count the reasons
+    uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on
 };
 
-// prefix-score bounds of a 16-step block (k4_device.h, bound_window): v / dh / cg = the block's columns in the low
-// half-word
-__device__ __forceinline__ void bound_block(Bound &B, uint32_t v, uint32_t dh, uint32_t cg, int xdrop) {
-    const uint32_t b = v & dh, a = cg & ~(v | dh);
-    const int32_t dv = __popc(v), db = __popc(b), dt = __popc(dh) - db, da = __popc(a);
-    B.ub = max(B.ub, B.U + 100 * (16 - dv - dt));
-    B.U += 91 * 16 + 9 * da - 122 * dt - 205 * dv - 9 * db;
-    B.nb += db;
-    B.stop = B.stop || (B.U + xdrop < B.lomax);
-    B.lomax = max(B.lomax, B.U - 2 * B.nb);
+// ---- pre-filter on two frames in the common alignment ------------------------------------------------------
+// left walk = frame bits 127 .. 32 (six 16-step blocks), right walk = bits 128 .. 191 (four blocks); the seed windows
+// that END where left step s arrives start at bit 108 - s.  A pair is dismissed when (i) both walks provably stop
+// inside the frame, (ii) no earlier seed hit of the diagonal can end at a boundary the left walk reaches before its
+// proven stop, so the hit is a head, and (iii) an upper bound of best(left) + best(right) is below hspthresh: the exact
+// walk would then find an isolated head that scores too little, and emit nothing.  Everything else goes to the batch's
+// walk queue (k4_walk_queue: the exact walk).  The proofs use the CHEAP bounds — two popcounts per block: n =
+// mismatching columns, v = transversions; a match scores 91..100, a transition -31, a transversion -125..-114 — and
+// a seed test on ten of the twelve care positions without the transition rule: 3.8 % of random hits are walked
+// instead of 1.4 % with the sharpest bounds, for 40 % fewer instructions per pair (scripts/dev_filter_mc.py; the
+// kernel is bound by VALU issue, and popcounts, funnel shifts, compares and max issue at half rate).
+struct Bound2 {
+    int32_t up, lomax, ub;   // upper bound of the prefix score; best lower bound at an earlier checkpoint; bound of the best prefix
+    bool stop;
+};
+__device__ __forceinline__ void bound_block2(Bound2 &B, uint32_t v16, uint32_t n16, int32_t &lo, int xdrop) {
+    const int32_t pv = __popc(v16), pn = __popc(n16);
+    B.ub = max(B.ub, B.up + 1600 - 100 * pn);
+    B.up += 1600 - 131 * pn - 83 * pv;
+    lo += 1456 - 122 * pn - 94 * pv;
+    B.stop = B.stop || (B.up + xdrop < B.lomax);
+    B.lomax = max(B.lomax, lo);
 }
 
-// SUPERSET of "a seed hit of this diagonal starts at frame bit B + i" for i = 0 .. 31 (bit i of the result): ten of
-// the twelve care positions (0.1 % false alarms over the 96 starts of a frame; eight gave 2.9 %), no seed-validity
-// planes — a false alarm only sends the pair to the exact walk.
-// n0 / n1: the words of nm = dl | dh that hold bits B - 13 .. B + 50 (B = 13 + 32 k); d0 / d1: the same of dl.
-__device__ __forceinline__ uint32_t seed_alarm32(uint32_t n0, uint32_t n1, uint32_t d0, uint32_t d1, int transitions) {
+// "a seed hit of this diagonal may start at frame bit B + i" for i = 0 .. 31 (bit i of the result), B = 13 + 32 k.
+// n0 / n1: the words of nm = dl | dh that hold bits B - 13 .. B + 50; d0 / d1: the same of dl.  CARE = the care
+// positions looked at (all twelve + TV: the exact 12of19 rule with one transition; fewer / no TV: a superset).
+template <uint32_t CARE, bool TV>
+__device__ __forceinline__ uint32_t seed_starts32(uint32_t n0, uint32_t n1, uint32_t d0, uint32_t d1, int transitions) {
     uint32_t ones = 0, twos = 0, tv = 0;
 #pragma unroll
     for (int c = 0; c < SEED_LEN; c++) {
-        if (!((CARE10 >> c) & 1u)) continue;
+        if (!((CARE >> c) & 1u)) continue;
         const uint32_t v = __builtin_amdgcn_alignbit(n1, n0, 13 + c);
         twos |= ones & v;
         ones |= v;
-        tv |= __builtin_amdgcn_alignbit(d1, d0, 13 + c);
+        if (TV) tv |= __builtin_amdgcn_alignbit(d1, d0, 13 + c);
     }
     return ~(transitions ? (twos | tv) : ones);
 }
 
-// true = the pair needs the exact walk.  Same three proofs as hit_needs_walk (k4_device.h) on frames in the common
-// alignment: left walk = frame bits 127 .. 32 (six blocks), right walk = bits 128 .. 191 (four blocks), seed windows
-// that end where left step s arrives start at bit 108 - s.
+// true = the pair is walked exactly
 __device__ __forceinline__ bool pair_needs_walk(const uint4 t0, const uint4 t1, const uint4 t2, const uint4 q0, const uint4 q1,
-                                                const uint4 q2, int xdrop, int hspthresh, int transitions, uint32_t *why = nullptr) {
+                                                const uint4 q2, int xdrop, int hspthresh, int transitions) {
     // planes: lo = {0.x 0.y 0.z 0.w 1.x 1.y}, hi = {1.z 1.w 2.x 2.y 2.z 2.w}
     const uint32_t dl0 = t0.x ^ q0.x, dl1 = t0.y ^ q0.y, dl2 = t0.z ^ q0.z, dl3 = t0.w ^ q0.w, dl4 = t1.x ^ q1.x, dl5 = t1.y ^ q1.y;
-    const uint32_t dh0 = t1.z ^ q1.z, dh1 = t1.w ^ q1.w, dh2 = t2.x ^ q2.x, dh3 = t2.y ^ q2.y, dh4 = t2.z ^ q2.z, dh5 = t2.w ^ q2.w;
-    const uint32_t cg1 = t0.y ^ t1.w, cg2 = t0.z ^ t2.x, cg3 = t0.w ^ t2.y, cg4 = t1.x ^ t2.z, cg5 = t1.y ^ t2.w;
+    const uint32_t n0 = dl0 | (t1.z ^ q1.z), n1 = dl1 | (t1.w ^ q1.w), n2 = dl2 | (t2.x ^ q2.x), n3 = dl3 | (t2.y ^ q2.y),
+                   n4 = dl4 | (t2.z ^ q2.z), n5 = dl5 | (t2.w ^ q2.w);
     // earlier seed hits: starts 77..108 <-> left steps 31..0, 45..76 <-> steps 63..32, 13..44 <-> steps 95..64
-    const uint32_t n0 = dl0 | dh0, n1 = dl1 | dh1, n2 = dl2 | dh2, n3 = dl3 | dh3;
-    const uint32_t h0 = seed_alarm32(n2, n3, dl2, dl3, transitions);   // bit 31 - s  <-> step s      (s = 0..31)
-    const uint32_t h1 = seed_alarm32(n1, n2, dl1, dl2, transitions);   // bit 63 - s  <-> step s      (s = 32..63)
-    const uint32_t h2 = seed_alarm32(n0, n1, dl0, dl1, transitions);   // bit 95 - s  <-> step s      (s = 64..95)
-    Bound L{0, 0, 0, 0, false}, R{0, 0, 0, 0, false};
+    const uint32_t h0 = seed_starts32<CARE10, false>(n2, n3, 0u, 0u, transitions);   // bit 31 - s  <-> step s      (s = 0..31)
+    const uint32_t h1 = seed_starts32<CARE10, false>(n1, n2, 0u, 0u, transitions);   // bit 63 - s  <-> step s      (s = 32..63)
+    const uint32_t h2 = seed_starts32<CARE10, false>(n0, n1, 0u, 0u, transitions);   // bit 95 - s  <-> step s      (s = 64..95)
+    Bound2 L{0, 0, 0, false}, R{0, 0, 0, false};
+    int32_t llo = 0, rlo = 0;
     uint32_t veto = 0;
     // a boundary only counts while the walk is not yet proven to have stopped
-    veto |= h0 >> 16;                        bound_block(L, dl3 >> 16, dh3 >> 16, cg3 >> 16, xdrop);
-    veto |= L.stop ? 0u : (h0 & 0xFFFFu);    bound_block(L, dl3 & 0xFFFFu, dh3 & 0xFFFFu, cg3 & 0xFFFFu, xdrop);
-    veto |= L.stop ? 0u : (h1 >> 16);        bound_block(L, dl2 >> 16, dh2 >> 16, cg2 >> 16, xdrop);
-    veto |= L.stop ? 0u : (h1 & 0xFFFFu);    bound_block(L, dl2 & 0xFFFFu, dh2 & 0xFFFFu, cg2 & 0xFFFFu, xdrop);
-    veto |= L.stop ? 0u : (h2 >> 16);        bound_block(L, dl1 >> 16, dh1 >> 16, cg1 >> 16, xdrop);
-    veto |= L.stop ? 0u : (h2 & 0xFFFFu);    bound_block(L, dl1 & 0xFFFFu, dh1 & 0xFFFFu, cg1 & 0xFFFFu, xdrop);
-    bound_block(R, dl4 & 0xFFFFu, dh4 & 0xFFFFu, cg4 & 0xFFFFu, xdrop);
-    bound_block(R, dl4 >> 16, dh4 >> 16, cg4 >> 16, xdrop);
-    bound_block(R, dl5 & 0xFFFFu, dh5 & 0xFFFFu, cg5 & 0xFFFFu, xdrop);
-    bound_block(R, dl5 >> 16, dh5 >> 16, cg5 >> 16, xdrop);
-    if (why) *why = (L.stop ? 0u : 1u) | (R.stop ? 0u : 2u) | (L.ub + R.ub < hspthresh ? 0u : 4u) | (veto ? 8u : 0u);
+    veto |= h0 >> 16;                        bound_block2(L, dl3 >> 16, n3 >> 16, llo, xdrop);
+    veto |= L.stop ? 0u : (h0 & 0xFFFFu);    bound_block2(L, dl3 & 0xFFFFu, n3 & 0xFFFFu, llo, xdrop);
+    veto |= L.stop ? 0u : (h1 >> 16);        bound_block2(L, dl2 >> 16, n2 >> 16, llo, xdrop);
+    veto |= L.stop ? 0u : (h1 & 0xFFFFu);    bound_block2(L, dl2 & 0xFFFFu, n2 & 0xFFFFu, llo, xdrop);
+    veto |= L.stop ? 0u : (h2 >> 16);        bound_block2(L, dl1 >> 16, n1 >> 16, llo, xdrop);
+    veto |= L.stop ? 0u : (h2 & 0xFFFFu);    bound_block2(L, dl1 & 0xFFFFu, n1 & 0xFFFFu, llo, xdrop);
+    bound_block2(R, dl4 & 0xFFFFu, n4 & 0xFFFFu, rlo, xdrop);
+    bound_block2(R, dl4 >> 16, n4 >> 16, rlo, xdrop);
+    bound_block2(R, dl5 & 0xFFFFu, n5 & 0xFFFFu, rlo, xdrop);
+    bound_block2(R, dl5 >> 16, n5 >> 16, rlo, xdrop);
     return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
 }
 
@@ -137,19 +149,23 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
         return;
     }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] -= q0;   // offsets relative to the tile's first query entry
+    const bool single = nQ <= QSEG;   // the whole query tile in one segment: no clipping of the neighbour ranges
     uint32_t *sD = sD_all + wv * DQ;
     uint2 *s_walk = s_walk_all + wv * 64;
     uint32_t n_walk = 0;
     unsigned long long wave_hits = 0;
     const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
 
-    // the walk queue takes the staged survivors 64 at a time (one atomic per flush)
+    // the pairs the filter passed on go to the batch's walk queue, 64 at a time (one atomic per flush)
     auto flush_walk = [&](uint32_t n) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(&A.q.ctr->nwalk, (unsigned long long)n);
+        const uint32_t shard = blockIdx.x & 7u;
+        if (lane == 0) b = atomicAdd(&A.q.ctr->nwalk[shard], (unsigned long long)n);
         b = __shfl(b, 0);
-        if (lane < n && b + lane < A.q.walk_cap) { A.q.walkq[b + lane] = s_walk[lane]; A.q.walku[b + lane] = A.unit; }
+        if (lane < n && b + lane < A.q.walk_cap) A.q.walkq[(size_t)shard * A.q.walk_cap + b + lane] = s_walk[lane];
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -193,10 +209,19 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             if (tvalid) {
                 w = pext12(f2.y >> 13);
                 const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
-                for (int j = 0; j < nn; j++) {
-                    const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                    const uint32_t a = max(sQ[w2] - q0, qs), b = min(sQ[w2 + 1] - q0, qe);
-                    if (a < b) { c += b - a; nmask |= 1u << j; }
+                if (single) {
+                    for (int j = 0; j < nn; j++) {
+                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                        const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                        c += b - a;
+                        nmask |= (b != a ? 1u : 0u) << j;
+                    }
+                } else {
+                    for (int j = 0; j < nn; j++) {
+                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                        const uint32_t a = max(sQ[w2], qs), b = min(sQ[w2 + 1], qe);
+                        if (a < b) { c += b - a; nmask |= 1u << j; }
+                    }
                 }
             }
             uint32_t inc = c;
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     for (uint32_t m = nmask; m; m &= m - 1u) {
                         const uint32_t j = (uint32_t)__builtin_ctz(m);
                         const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
-                        const uint32_t a = max(sQ[w2] - q0, qs), b = min(sQ[w2 + 1] - q0, qe);
+                        const uint32_t a = max(sQ[w2], qs), b = min(sQ[w2 + 1], qe);
                         const uint32_t g0 = max(acc, rb), g1 = min(acc + (b - a), rb + DQ);
                         for (uint32_t g = g0; g < g1; g++) sD[g - rb] = (lane << 16) | (a + (g - acc) - qs);
                         acc += b - a;
@@ -233,28 +258,13 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                         if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
                         else need = ((tpf >> 31) | sQN[qi]) != 0 ||
                                     pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
-#ifdef MIMEO_K34_WHY
-                        if ((A.dbg & 8u) && need) {
-                            uint32_t why = 0;
-                            pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions, &why);
-                            if (why & 1u) atomicAdd(&A.q.ctr->dbg[0], 1ull);
-                            if (why & 2u) atomicAdd(&A.q.ctr->dbg[1], 1ull);
-                            if (why & 4u) atomicAdd(&A.q.ctr->dbg[2], 1ull);
-                            if (why & 8u) atomicAdd(&A.q.ctr->dbg[3], 1ull);
-                            if (why == 8u) atomicAdd(&A.q.ctr->dbg[4], 1ull);
-                            if (why == 1u) atomicAdd(&A.q.ctr->dbg[5], 1ull);
-                            if (why == 2u) atomicAdd(&A.q.ctr->dbg[6], 1ull);
-                            if (why == 4u) atomicAdd(&A.q.ctr->dbg[7], 1ull);
-                        }
-#endif
                         if (A.dbg & 2u) need = false;
                     }
-                    const uint32_t tp = tpf & POS_MASK;
                     uint32_t qp = 0;
                     if (A.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
                         if (valid) {
                             qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
-                            if (tp == qp) need = false;
+                            if ((tpf & POS_MASK) == qp) need = false;
                         }
                     } else if (need) {
                         qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     if (m) {
                         const uint32_t add = (uint32_t)__popcll(m);
                         if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
-                        if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tp, qp);
+                        if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
                         n_walk += add;
                     }
                 }
@@ -310,9 +320,9 @@ static int launch_cfg(const FusedArgs &A, hipStream_t st) {
 
 int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
                       hipStream_t st) {
-    (void)tab;
     FusedArgs A;
-    A.T = w.ti; A.Q = w.qi; A.q = q;
+    A.T = w.ti; A.Q = w.qi; A.q = q; A.tab = tab;
+    A.tlen = w.d.T.len; A.qlen = w.d.Q.len; A.tsoft = w.d.T.svt != nullptr ? 1u : 0u;
     A.unit = unit; A.same = w.d.same;
     A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
     A.dbg = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
@@ -320,7 +330,8 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
     // two passes), or two 512-thread workgroups per CU with 1024-entry segments (scaffolds up to ~5 Mbp: one pass)
     static const int cfg = getenv("MIMEO_K34_CFG") ? atoi(getenv("MIMEO_K34_CFG")) : 0;
     const uint32_t avg = (uint32_t)(((uint64_t)w.qi.n + NTILE - 1) / NTILE);
-    const bool big = cfg ? cfg == 1 : avg > 900;
+    const bool big = cfg ? cfg == 1 : false;  // measured: two 512-thread workgroups per CU win on 10 Mbp tiles too (1.30 vs 1.62 ms per C4 unit)
+    (void)avg;
     return big ? launch_cfg<1024, 2048>(A, st) : launch_cfg<512, 1024>(A, st);
 }
 

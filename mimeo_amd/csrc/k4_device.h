@@ -16,7 +16,11 @@ constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per 
 // kernels look the two strands up in the unit table.
 struct ExtCounters {
     unsigned long long ncand, nfollow, nlong, nhsp, nmed, nbig, nwalked;  // nwalked: hits the pre-filter let through
-    unsigned long long nwalk;   // entries of the walk queue (K34 -> k4_walk_queue)
+    unsigned long long nwalk[8];   // entries of the walk queue of the current unit (K34 -> k4_extend_hits on the queue), in eight
+                                   // shards (workgroup number mod 8, i.e. per XCD): 50 000 flushes per unit on ONE counter
+                                   // would serialise at ~13 ns each
+    unsigned long long nbigcand;   // candidates longer than ENT_LONG columns: their entropy is counted by the whole grid
+    unsigned long long nwalk_total, nwalk_over;  // ... summed over the batch; largest shard count that exceeded a shard's capacity
     unsigned long long dbg[8];  // development (MIMEO_K34_DEBUG & 8): why the pre-filter passed a hit on
 };
 
@@ -38,13 +42,24 @@ struct ExtQueues {
     uint32_t *fprev;
     uint2 *medq, *longq;      // hits whose walk outlives the frame / LONG_WINDOWS windows
     uint32_t *medu, *longu;   // ... and their units
-    uint2 *walkq;             // hits the pre-filter of K34 could not dismiss: walked exactly by k4_walk_queue
-    uint32_t *walku;
+    uint2 *walkq;             // hits of the current unit that the pre-filter of K34 could not dismiss
+    unsigned long long *bigcand;    // indices of the long candidates (ENT_BIGCAP) and their accumulators: 5 per candidate
+    unsigned long long *bigacc;     // ... matched A / C / G / T columns, raw score
     unsigned long long *unit_hits;  // seed hits per unit (statistics)
     unsigned long long *tile_hits;  // ... per unit and tile (K34 writes them, k34_sum_hits folds them into unit_hits)
-    uint64_t cand_cap, follow_cap, med_cap, long_cap, walk_cap;
+    uint64_t cand_cap, follow_cap, med_cap, long_cap, walk_cap;   // walk_cap: per shard (shard r = walkq[r * walk_cap ...])
     uint32_t ebits, dbits;
 };
+// a slot of an append-only queue for every lane that calls this together: one atomic per wavefront (same-address
+// atomics serialise at ~13 ns each)
+__device__ __forceinline__ unsigned long long wave_slot(unsigned long long *counter) {
+    const uint64_t m = __ballot(true);   // the lanes active here
+    const uint32_t lane = threadIdx.x & 63u, lead = (uint32_t)__builtin_ctzll(m);
+    unsigned long long b = 0;
+    if (lane == lead) b = atomicAdd(counter, (unsigned long long)__popcll(m));
+    b = __shfl(b, (int)lead);
+    return b + __popcll(m & ((1ull << lane) - 1ull));
+}
 __device__ __forceinline__ uint64_t follow_key(const ExtQueues &q, uint32_t unit, int32_t d, uint32_t qlen, uint32_t et) {
     return ((uint64_t)unit << (q.dbits + q.ebits)) | ((uint64_t)(uint32_t)(d + (int32_t)qlen) << q.ebits) | (uint64_t)et;
 }
@@ -103,22 +118,25 @@ struct WalkState {
     uint32_t found_step;  // step index (1-based) whose boundary carries an earlier seed hit
 };
 
-// up to 32 steps of a walk whose masks are in step order (bit s <-> step s of this window)
+// up to 32 steps of a walk whose masks are in step order (bit s <-> step s of this window).  G = columns per table
+// group: 4 (4096-entry table, 16 KiB) or 2 (64 entries: fits beside the frames in the LDS of the fused kernel).
+template <int G = 4>
 __device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl, uint32_t mdh,
                                             uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit, int xdrop,
                                             uint32_t start = 0) {
+    constexpr uint32_t GM = (1u << G) - 1u;
     for (uint32_t pos = start; pos < 32;) {
         const uint32_t rem = limit - w.k;
         if (rem == 0) { w.done = true; return; }
-        if (rem >= 4 && pos <= 28 && !(((mnn | mH) >> pos) & 0xFu)) {
-            const uint32_t idx = ((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8);
+        if (rem >= (uint32_t)G && pos <= 32u - G && !(((mnn | mH) >> pos) & GM)) {
+            const uint32_t idx = ((mdl >> pos) & GM) | (((mdh >> pos) & GM) << G) | (((mcg >> pos) & GM) << (2 * G));
             const uint32_t e = tab[idx];
             const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
             if (w.run + mn < w.best - xdrop) { w.done = true; return; }
             if (w.run + M > w.best) { w.best = w.run + M; w.bk = w.k + (e >> 30) + 1; }
             w.run += S;
-            w.k += 4;
-            pos += 4;
+            w.k += G;
+            pos += G;
         } else {
             w.k++;
             w.run += sub_score((mdl >> pos) & 1u, (mdh >> pos) & 1u, (mcg >> pos) & 1u, (mnn >> pos) & 1u);
@@ -130,35 +148,39 @@ __device__ __forceinline__ void walk_window(const uint32_t *__restrict__ tab, Wa
     }
 }
 
-// The same 32 steps as walk_window, as straight-line code without per-lane branches: the eight table
+// The same 32 steps as walk_window, as straight-line code without per-lane branches: the table
 // groups are applied to running values unconditionally, and the state in front of the first group that
 // cannot be applied — x-drop inside it, an N / earlier seed hit / the sequence end in it, or a walk that
 // was already finished — is kept aside (one select per value and group).  A lane stopped by a blocked
 // group finishes the window in walk_window (rare; taken under a wave-uniform branch).
+template <int G = 4>
 __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ tab, WalkState &w, uint32_t mdl,
                                                  uint32_t mdh, uint32_t mcg, uint32_t mnn, uint32_t mH, uint32_t limit,
                                                  int xdrop) {
+    constexpr uint32_t GM = (1u << G) - 1u;
+    constexpr int NG = 32 / G, LOG = G == 4 ? 2 : 1;
+    static_assert(G == 4 || G == 2, "group size");
     const uint32_t blocked = mnn | mH;
-    // the eight table entries depend only on the masks: fetch them back to back, then run the
+    // the table entries depend only on the masks: fetch them back to back, then run the
     // dependent score arithmetic on registers
-    uint32_t ent[8];
+    uint32_t ent[NG];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const int pos = 4 * c;
-        ent[c] = tab[((mdl >> pos) & 0xFu) | (((mdh >> pos) & 0xFu) << 4) | (((mcg >> pos) & 0xFu) << 8)];
+    for (int c = 0; c < NG; c++) {
+        const int pos = G * c;
+        ent[c] = tab[((mdl >> pos) & GM) | (((mdh >> pos) & GM) << G) | (((mcg >> pos) & GM) << (2 * G))];
     }
     uint32_t nz = blocked | (blocked >> 1);
-    nz |= nz >> 2;                                // bit 4c: group c holds a blocked step ...
-    const uint32_t ng = (limit - w.k) >> 2;       // ... or does not fit below the limit any more (one test per
-    nz |= ng >= 8u ? 0u : (0xFFFFFFFFu << (4u * ng));  // group instead of two: compares issue at half rate)
+    if (G == 4) nz |= nz >> 2;                    // bit G c: group c holds a blocked step ...
+    const uint32_t ng = (limit - w.k) >> LOG;     // ... or does not fit below the limit any more (one test per
+    nz |= ng >= (uint32_t)NG ? 0u : (0xFFFFFFFFu << ((uint32_t)G * ng));  // group instead of two: compares issue at half rate)
     int32_t R = w.run, B = w.best, sR = R, sB = B;
     uint32_t BK = 0, sBK = 0, sC = 0;             // BK: steps at the best prefix relative to w.k (0 = unchanged)
     bool stopped = w.done, slow = false, brkdone = false;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
+    for (int c = 0; c < NG; c++) {
         const uint32_t e = ent[c];
         const int32_t S = ((int32_t)(e << 22)) >> 22, M = ((int32_t)(e << 12)) >> 22, mn = ((int32_t)(e << 2)) >> 22;
-        const bool blk = (nz >> (4 * c)) & 1u;
+        const bool blk = (nz >> (G * c)) & 1u;
         const bool brk = R + mn + xdrop < B;
         const bool first = (blk || brk) && !stopped;
         sR = first ? R : sR;
@@ -169,19 +191,33 @@ __device__ __forceinline__ void walk_window_pred(const uint32_t *__restrict__ ta
         brkdone = brkdone || (first && !blk);
         stopped = stopped || blk || brk;
         const int32_t cand = R + M;
-        BK = cand > B ? (e >> 30) + (uint32_t)(4 * c + 1) : BK;
+        BK = cand > B ? (e >> 30) + (uint32_t)(G * c + 1) : BK;
         B = max(B, cand);
         R += S;
     }
-    if (!stopped) { sR = R; sB = B; sBK = BK; sC = 8; }
+    if (!stopped) { sR = R; sB = B; sBK = BK; sC = NG; }
     w.run = sR;
     w.best = sB;
     w.bk = sBK ? w.k + sBK : w.bk;
-    w.k += 4u * sC;
+    w.k += (uint32_t)G * sC;
     w.done = w.done || brkdone;
     if (__ballot(slow)) {
-        if (slow) walk_window(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, 4u * sC);
+        if (slow) walk_window<G>(tab, w, mdl, mdh, mcg, mnn, mH, limit, xdrop, (uint32_t)G * sC);
     }
+}
+
+// entry idx of the group table for G columns per group, computed on the device (the fused kernel builds the
+// 64-entry table of G = 2 in LDS): score sum S, best prefix M and where, lowest prefix mn, packed as above
+template <int G>
+__device__ __forceinline__ uint32_t group_table_entry(uint32_t idx) {
+    int32_t p = 0, M = -100000, mn = 100000, posM = 0;
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        p += sub_score((idx >> k) & 1u, (idx >> (G + k)) & 1u, (idx >> (2 * G + k)) & 1u, 0u);
+        if (p > M) { M = p; posM = k; }
+        if (p < mn) mn = p;
+    }
+    return ((uint32_t)p & 0x3FFu) | (((uint32_t)M & 0x3FFu) << 10) | (((uint32_t)mn & 0x3FFu) << 20) | ((uint32_t)posM << 30);
 }
 
 // ---- K4a fast path: the whole neighbourhood of a hit is loaded once ---------------------------

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
                         __brev(H), maxl, xdrop);
         }
         if (!is_long && L.found) {
-            unsigned long long i = atomicAdd(&q.ctr->nfollow, 1ull);
+            const unsigned long long i = wave_slot(&q.ctr->nfollow);   // one atomic for the lanes that are here together
             if (i < q.follow_cap) {
                 q.fkey[i] = follow_key(q, unit, d, Q.len, (uint32_t)et);
                 q.fprev[i] = (uint32_t)et - L.found_step;  // position of the base just summed = that seed's end
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
             }
         }
         if (is_long) {
-            unsigned long long i = atomicAdd(&q.ctr->nlong, 1ull);
+            const unsigned long long i = wave_slot(&q.ctr->nlong);
             if (i < q.long_cap) { q.longq[i] = h; q.longu[i] = unit; }
             continue;
         }
         const int32_t score = L.best + R.best;
         if (score >= hspthresh) {
-            unsigned long long i = atomicAdd(&q.ctr->ncand, 1ull);
+            const unsigned long long i = wave_slot(&q.ctr->ncand);
             if (i < q.cand_cap) q.cand[i] = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, score, unit};
         }
     }
@@ -118,8 +118,18 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                                                               const uint2 *__restrict__ hits, uint64_t nhits,
                                                               int xdrop, int hspthresh, int transitions,
                                                               const uint32_t *__restrict__ group_tab, ExtQueues q, uint32_t unit,
-                                                              int skip_diag0) {
+                                                              int skip_diag0, const unsigned long long *__restrict__ nhits_dev) {
     constexpr bool FILTER = VARIANT == 5 || VARIANT == 9;
+    // nhits_dev: the hits are the walk queue of this unit, filled by K34 just before on the same stream: eight shards of
+    // capacity `nhits` each, the counts on the device.  sh_end[r] = hits in shards 0 .. r.
+    uint64_t sh_end[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t shard_cap = nhits;
+    if (nhits_dev) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { acc += min((uint64_t)nhits_dev[r], shard_cap); sh_end[r] = acc; }
+        nhits = acc;
+    }
     __shared__ uint32_t tab[GROUP_TAB];
     __shared__ uint2 s_med[FAST_THREADS / 64][QCAP];
     __shared__ uint64_t s_fk[FAST_THREADS / 64][QCAP];
@@ -146,7 +156,16 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
     for (uint64_t g0 = (uint64_t)blockIdx.x * FAST_THREADS + wv * 64u; g0 < nhits; g0 += stride) {
         const uint64_t gid = g0 + lane;
         uint2 h = make_uint2(0, 0);
-        if (gid < nhits) h = hits[gid];
+        if (gid < nhits) {
+            uint64_t at = gid;
+            if (nhits_dev) {   // flat index -> (shard, index in the shard)
+                uint32_t r = 0;
+#pragma unroll
+                for (int k = 0; k < 7; k++) r += gid >= sh_end[k] ? 1u : 0u;
+                at = (uint64_t)r * shard_cap + (gid - (r ? sh_end[r - 1] : 0));
+            }
+            h = hits[at];
+        }
         const bool valid = gid < nhits && !(skip_diag0 && h.x == h.y);  // the main diagonal of a self unit belongs to k4_diag0
         if (!FILTER) {
             walk_batch(valid, h, false);
@@ -179,52 +198,17 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
     }
     if (FILTER && n_walked && lane == 0) atomicAdd(&q.ctr->nwalked, (unsigned long long)n_walked);
     walk_batch(false, make_uint2(0, 0), true);  // flush the staged records
-    if (blockIdx.x == 0 && threadIdx.x == 0) q.unit_hits[unit] = nhits;
+    if (!nhits_dev && blockIdx.x == 0 && threadIdx.x == 0) q.unit_hits[unit] = nhits;
 }
 
-// ---- exact walks of the hits the fused kernel (K34) could not dismiss, once per batch ---------------------------
-// Same walk as k4_extend_hits<1>, the hits come tagged with their unit.  Units run one after the other, so the 64
-// hits of a wavefront nearly always share a unit; records are staged per wavefront and flushed per unit.
-__global__ __launch_bounds__(FAST_THREADS) void k4_walk_queue(const UnitDesc *__restrict__ units, ExtQueues q, int xdrop, int hspthresh,
-                                                             int transitions, const uint32_t *__restrict__ group_tab) {
-    __shared__ uint32_t tab[GROUP_TAB];
-    __shared__ uint2 s_med[FAST_THREADS / 64][QCAP];
-    __shared__ uint64_t s_fk[FAST_THREADS / 64][QCAP];
-    __shared__ uint32_t s_fp[FAST_THREADS / 64][QCAP];
-    __shared__ Cand s_cd[FAST_THREADS / 64][QCAP];
-    for (int i = threadIdx.x; i < GROUP_TAB; i += FAST_THREADS) tab[i] = group_tab[i];
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint64_t n = min((uint64_t)q.ctr->nwalk, q.walk_cap);
-    WaveFill fill{0, 0, 0};
-    uint32_t cur = 0xFFFFFFFFu;  // unit of the staged records (wave-uniform)
-    const uint64_t stride = (uint64_t)gridDim.x * FAST_THREADS;
-    for (uint64_t g0 = (uint64_t)blockIdx.x * FAST_THREADS + wv * 64u; g0 < n; g0 += stride) {
-        const uint64_t gid = g0 + lane;
-        const bool valid = gid < n;
-        const uint2 h = valid ? q.walkq[gid] : make_uint2(0, 0);
-        const uint32_t u = valid ? q.walku[gid] : 0xFFFFFFFFu;
-        // sub-batches by unit (one, except where the queue passes from a unit to the next)
-        uint64_t todo = __ballot(valid);
-        while (todo) {
-            const uint32_t uu = (uint32_t)__shfl((int)u, __builtin_ctzll(todo));
-            const bool mine = valid && u == uu;
-            todo &= ~__ballot(mine);
-            if (uu != cur) {
-                if (cur != 0xFFFFFFFFu)
-                    stage_records<true>(q, cur, s_med[wv], s_fk[wv], s_fp[wv], s_cd[wv], fill, false, h, false, 0, 0, false, Cand{0, 0, 0, 0, 0}, true);
-                cur = uu;
-            }
-            bool q_med = false, q_fol = false, q_cd = false;
-            uint64_t r_fk = 0;
-            uint32_t r_fp = 0;
-            Cand r_cd{0, 0, 0, 0, 0};
-            if (mine) walk_hit<1>(tab, units[uu].T, units[uu].Q, h, xdrop, hspthresh, transitions, q_med, q_fol, q_cd, r_fk, r_fp, r_cd);
-            stage_records<true>(q, uu, s_med[wv], s_fk[wv], s_fp[wv], s_cd[wv], fill, q_med, h, q_fol, r_fk, r_fp, q_cd, r_cd, false);
-        }
+// the walk queue of a unit has been worked off: empty it for the next unit, keep the statistics and the overflow mark
+__global__ void k4_queue_reset(ExtCounters *ctr, uint64_t cap) {
+    for (int r = 0; r < 8; r++) {
+        const unsigned long long n = ctr->nwalk[r];
+        ctr->nwalk_total += n;
+        if (n > cap) ctr->nwalk_over = max(ctr->nwalk_over, n);
+        ctr->nwalk[r] = 0;
     }
-    if (cur != 0xFFFFFFFFu)
-        stage_records<true>(q, cur, s_med[wv], s_fk[wv], s_fp[wv], s_cd[wv], fill, false, make_uint2(0, 0), false, 0, 0, false, Cand{0, 0, 0, 0, 0}, true);
 }
 
 // ---- long hits, one wavefront each ------------------------------------------------------------------------
@@ -297,11 +281,11 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(const UnitDesc *
         }
     }
     if (big) {  // nothing has been emitted for this segment yet: the wavefront kernel redoes it
-        bigseg[atomicAdd(&q.ctr->nbig, 1ull)] = sid;
+        bigseg[wave_slot(&q.ctr->nbig)] = sid;
         return;
     }
     for (uint32_t k = 0; k < nout; k++) {
-        unsigned long long i = atomicAdd(&q.ctr->ncand, 1ull);
+        const unsigned long long i = wave_slot(&q.ctr->ncand);
         if (i < q.cand_cap) q.cand[i] = out[k];
     }
 }
@@ -383,52 +367,69 @@ __global__ __launch_bounds__(64) void k4_diag0(const UnitDesc *__restrict__ unit
     }
 }
 
-// ---- entropy adjustment + threshold, one wavefront per candidate ---------------------------------------------
+// ---- entropy adjustment + threshold: eight lanes per candidate ------------------------------------------------
+// A C4 row has 1.5 M candidates, nearly all of them 30-300 columns long: a group of eight lanes takes one (256
+// columns per step, reductions over three xor-shuffles), so a wavefront finishes eight candidates at a time; the
+// few long ones (the main diagonal of a self unit: millions of columns) just take more steps of their group.
+constexpr uint32_t ENT_LANES = 8;
+constexpr uint32_t ENT_LONG = 1u << 16;     // columns: longer candidates (the main diagonal of a self unit: the whole scaffold) ...
+constexpr uint32_t ENT_BIGCAP = 4096;       // ... are counted by the whole grid (k4_entropy_big), up to this many per batch
 __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(const UnitDesc *__restrict__ units, ExtQueues q, int hspthresh,
                                                           int entropy, mimeo_hsp *__restrict__ out,
                                                           uint32_t *__restrict__ out_unit) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t ncand = min((uint64_t)q.ctr->ncand, q.cand_cap), nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
-    for (uint64_t cid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; cid < ncand; cid += nwaves) {
-    Cand c = q.cand[cid];
+    const uint32_t sub = threadIdx.x & (ENT_LANES - 1u);
+    const uint64_t ncand = min((uint64_t)q.ctr->ncand, q.cand_cap);
+    const uint64_t ngroups = ((uint64_t)gridDim.x * EXT_THREADS) / ENT_LANES;
+    // the loop bound is wave-uniform (rounded up to the wavefront's eight groups): the shuffles below need every lane
+    const uint64_t first = (((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) / 64) * (64 / ENT_LANES);
+    for (uint64_t base = first; base < ncand; base += ngroups) {
+    const uint64_t cid = base + (threadIdx.x & 63u) / ENT_LANES;
+    const bool live = cid < ncand;
+    Cand c = q.cand[live ? cid : ncand - 1];
+    if (!live) c.len = 0;
+    if (c.len > ENT_LONG) {   // one group of eight lanes would crawl through millions of columns with the wavefront waiting
+        unsigned long long slot = ENT_BIGCAP;
+        if (sub == 0) slot = wave_slot(&q.ctr->nbigcand);
+        slot = __shfl(slot, (int)((threadIdx.x & 63u) & ~(ENT_LANES - 1u)));
+        if (slot < ENT_BIGCAP) {
+            if (sub == 0) q.bigcand[slot] = cid;
+            c.len = 0;   // nothing to do here; k4_entropy_big emits it
+        }
+    }
+    const bool deferred = live && c.len == 0;
     const StrandView T = units[c.unit].T, Q = units[c.unit].Q;
     int64_t raw = c.raw;
     const int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
-    if (c.raw == RAW_SATURATED) {  // recount the column scores of the segment in 64 bits (wave-uniform, rare)
+    // the longest candidate of the wavefront sets the number of steps (wave-uniform loops: shuffles inside)
+    uint32_t maxlen = c.len;
+    for (int o = 32; o >= (int)ENT_LANES; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    if (__ballot(c.raw == RAW_SATURATED)) {  // recount the column scores of the segment in 64 bits (rare)
         int64_t sum = 0;
-        for (uint32_t o = lane * 32u; o < c.len; o += 64u * 32u) {
-            const int32_t pt = (int32_t)(c.tstart + o);
-            const Win32 tw = win32(T, pt), qw = win32(Q, pt - d);
-            const uint32_t rem = c.len - o, valid = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
-            const uint32_t nn = (tw.nm | qw.nm) & valid, dl = (tw.lo ^ qw.lo) & ~nn & valid, dh = (tw.hi ^ qw.hi) & ~nn & valid;
-            const uint32_t cg = tw.lo ^ tw.hi, ok = valid & ~nn;
-            sum += 91ll * __popc(ok) + 9ll * __popc(ok & ~(dl | dh) & cg) - 122ll * __popc(~dl & dh) - 205ll * __popc(dl) -
-                   9ll * __popc(dl & dh) - 2ll * __popc(dl & dh & cg) - 100ll * __popc(nn);
+        for (uint32_t o0 = 0; o0 < maxlen; o0 += ENT_LANES * 32u) {
+            const uint32_t o = o0 + sub * 32u;
+            if (o < c.len && c.raw == RAW_SATURATED) {
+                const int32_t pt = (int32_t)(c.tstart + o);
+                const Win32 tw = win32(T, pt), qw = win32(Q, pt - d);
+                const uint32_t rem = c.len - o, valid = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+                const uint32_t nn = (tw.nm | qw.nm) & valid, dl = (tw.lo ^ qw.lo) & ~nn & valid, dh = (tw.hi ^ qw.hi) & ~nn & valid;
+                const uint32_t cg = tw.lo ^ tw.hi, ok = valid & ~nn;
+                sum += 91ll * __popc(ok) + 9ll * __popc(ok & ~(dl | dh) & cg) - 122ll * __popc(~dl & dh) - 205ll * __popc(dl) -
+                       9ll * __popc(dl & dh) - 2ll * __popc(dl & dh & cg) - 100ll * __popc(nn);
+            }
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        raw = sum;
+        for (int o = ENT_LANES / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (c.raw == RAW_SATURATED) raw = sum;
     }
     int64_t adj = raw;
     if (entropy) {
         uint32_t cnt[4] = {0, 0, 0, 0};
-        // four independent windows per iteration: the loads of a long HSP overlap instead of queueing
-        for (uint32_t w0 = lane * 32u; w0 < c.len; w0 += 4u * 64u * 32u) {
-            Win32 tw[4], qw[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t o = w0 + (uint32_t)j * 64u * 32u;
-                if (o < c.len) {
-                    const int32_t pt = (int32_t)(c.tstart + o);
-                    tw[j] = win32(T, pt);
-                    qw[j] = win32(Q, pt - d);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t o = w0 + (uint32_t)j * 64u * 32u;
-                if (o >= c.len) break;
-                const uint32_t tlo = tw[j].lo, thi = tw[j].hi;
-                uint32_t m = ~((tlo ^ qw[j].lo) | (thi ^ qw[j].hi)) & ~(tw[j].nm | qw[j].nm);
+        for (uint32_t o0 = 0; o0 < maxlen; o0 += ENT_LANES * 32u) {
+            const uint32_t o = o0 + sub * 32u;
+            if (o < c.len) {
+                const int32_t pt = (int32_t)(c.tstart + o);
+                const Win32 tw = win32(T, pt), qw = win32(Q, pt - d);
+                const uint32_t tlo = tw.lo, thi = tw.hi;
+                uint32_t m = ~((tlo ^ qw.lo) | (thi ^ qw.hi)) & ~(tw.nm | qw.nm);
                 const uint32_t rem = c.len - o;
                 if (rem < 32) m &= (1u << rem) - 1u;
                 cnt[0] += __popc(m & ~tlo & ~thi);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(const UnitDesc *__rest
             }
         }
         for (int b = 0; b < 4; b++)
-            for (int o = 32; o > 0; o >>= 1) cnt[b] += __shfl_xor(cnt[b], o);
+            for (int o = ENT_LANES / 2; o > 0; o >>= 1) cnt[b] += __shfl_xor(cnt[b], o);
         uint64_t n = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
         double hh = 0.0;
         if (n) {
@@ -450,13 +451,91 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(const UnitDesc *__rest
         q16 = q16 > 65536 ? 65536 : (q16 < 0 ? 0 : q16);
         adj = (raw * q16) >> 16;
     }
-    if (adj >= hspthresh && lane == 0) {
-        unsigned long long i = atomicAdd(&q.ctr->nhsp, 1ull);
-        mimeo_hsp h;
-        h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = raw;
-        out[i] = h;   // at most one HSP per candidate: the buffers hold cand_cap records
-        out_unit[i] = c.unit;
+    // one atomic per wavefront and step (1.5 M same-address atomics per C4 row would serialise at ~13 ns each)
+    const bool emit = live && !deferred && adj >= hspthresh && sub == 0;
+    const uint64_t em = __ballot(emit);
+    if (em) {
+        const uint32_t lane = threadIdx.x & 63u;
+        unsigned long long b = 0;
+        if (lane == (uint32_t)__builtin_ctzll(em)) b = atomicAdd(&q.ctr->nhsp, (unsigned long long)__popcll(em));
+        b = __shfl(b, __builtin_ctzll(em));
+        if (emit) {
+            const unsigned long long i = b + __popcll(em & ((1ull << lane) - 1ull));
+            mimeo_hsp h;
+            h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = raw;
+            out[i] = h;   // at most one HSP per candidate: the buffers hold cand_cap records
+            out_unit[i] = c.unit;
+        }
     }
+    }
+}
+
+// the long candidates: every workgroup counts a slice (matched columns per base, and the raw score again in 64 bits
+// when it had saturated), then one lane per candidate applies the same formula as k4_entropy
+__global__ __launch_bounds__(256) void k4_entropy_big(const UnitDesc *__restrict__ units, ExtQueues q) {
+    const uint64_t nbig = min((uint64_t)q.ctr->nbigcand, (uint64_t)ENT_BIGCAP);
+    __shared__ unsigned long long red[5];
+    for (uint64_t bi = blockIdx.y; bi < nbig; bi += gridDim.y) {
+        const Cand c = q.cand[q.bigcand[bi]];
+        const StrandView T = units[c.unit].T, Q = units[c.unit].Q;
+        const int32_t d = (int32_t)c.tstart - (int32_t)c.qstart;
+        unsigned long long cnt[4] = {0, 0, 0, 0};
+        long long sum = 0;
+        for (uint64_t o = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 32u; o < c.len; o += (uint64_t)gridDim.x * 256 * 32u) {
+            const int32_t pt = (int32_t)(c.tstart + o);
+            const Win32 tw = win32(T, pt), qw = win32(Q, pt - d);
+            const uint32_t rem = (uint32_t)(c.len - o), valid = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+            const uint32_t nn = (tw.nm | qw.nm) & valid, dl = (tw.lo ^ qw.lo) & ~nn & valid, dh = (tw.hi ^ qw.hi) & ~nn & valid;
+            const uint32_t cg = tw.lo ^ tw.hi, ok = valid & ~nn, m = ok & ~(dl | dh);
+            cnt[0] += __popc(m & ~tw.lo & ~tw.hi);
+            cnt[1] += __popc(m & tw.lo & ~tw.hi);
+            cnt[2] += __popc(m & ~tw.lo & tw.hi);
+            cnt[3] += __popc(m & tw.lo & tw.hi);
+            sum += 91ll * __popc(ok) + 9ll * __popc(m & cg) - 122ll * __popc(~dl & dh & ok) - 205ll * __popc(dl) -
+                   9ll * __popc(dl & dh) - 2ll * __popc(dl & dh & cg) - 100ll * __popc(nn);
+        }
+        if (threadIdx.x < 5) red[threadIdx.x] = 0;
+        __syncthreads();
+        for (int k = 0; k < 4; k++) {
+            unsigned long long v = cnt[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
+        }
+        {
+            long long v = sum;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&red[4], (unsigned long long)v);
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) atomicAdd(&q.bigacc[bi * 5 + threadIdx.x], red[threadIdx.x]);
+        __syncthreads();
+    }
+}
+__global__ void k4_entropy_big_finish(ExtQueues q, int hspthresh, int entropy, mimeo_hsp *__restrict__ out, uint32_t *__restrict__ out_unit) {
+    const uint64_t nbig = min((uint64_t)q.ctr->nbigcand, (uint64_t)ENT_BIGCAP);
+    for (uint64_t bi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; bi < nbig; bi += (uint64_t)gridDim.x * blockDim.x) {
+        const Cand c = q.cand[q.bigcand[bi]];
+        const unsigned long long *a = q.bigacc + bi * 5;
+        int64_t raw = c.raw == RAW_SATURATED ? (int64_t)a[4] : (int64_t)c.raw, adj = raw;
+        if (entropy) {
+            const uint64_t n = a[0] + a[1] + a[2] + a[3];
+            double hh = 0.0;
+            if (n) {
+                for (int b = 0; b < 4; b++)
+                    if (a[b]) { double p = (double)a[b] / (double)n; hh -= p * log(p); }
+                hh /= log(4.0);
+            }
+            int64_t q16 = (int64_t)floor(hh * 65536.0 + 0.5);
+            q16 = q16 > 65536 ? 65536 : (q16 < 0 ? 0 : q16);
+            adj = (raw * q16) >> 16;
+        }
+        if (adj >= hspthresh) {
+            const unsigned long long i = atomicAdd(&q.ctr->nhsp, 1ull);
+            mimeo_hsp h;
+            h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = raw;
+            out[i] = h;
+            out_unit[i] = c.unit;
+        }
     }
 }
 
@@ -481,8 +560,8 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
 void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
-    for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &walku, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits})
+    for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -510,7 +589,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     const uint32_t *tab = group_table_device();
     if (!tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
     uint64_t max_t = 0, max_q = 0;
-    double expect_hits = 0;
+    double expect_hits = 0, max_unit_hits = 0;
     std::vector<UnitDesc> h_units(nunits);
     std::vector<uint32_t> h_selfs;
     for (uint32_t u = 0; u < nunits; u++) {
@@ -520,6 +599,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         max_t = std::max<uint64_t>(max_t, w.d.T.len);
         max_q = std::max<uint64_t>(max_q, w.d.Q.len);
         expect_hits += 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
+        max_unit_hits = std::max(max_unit_hits, 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0);
         if (w.d.same) h_selfs.push_back(u);
     }
     ExtQueues q;
@@ -540,7 +620,8 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     int rc;
     if ((rc = units.reserve((size_t)nunits * sizeof(UnitDesc))) || (rc = ctr.reserve(sizeof(ExtCounters))) ||
         (rc = unit_hits.reserve((size_t)nunits * 8)) || (rc = nsel.reserve(16)) ||
-        (rc = tile_hits.reserve(v1 ? 8 : (size_t)nunits * NTILE * 8)) ||
+        (rc = tile_hits.reserve(v1 ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) ||
+        (rc = bigacc.reserve((size_t)ENT_BIGCAP * 5 * 8)) ||
         (rc = selfs.reserve((h_selfs.size() + 1) * 4)))
         return rc;
     HIP_TRY(hipMemcpyAsync(units.p, h_units.data(), (size_t)nunits * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
@@ -555,26 +636,29 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     uint64_t cap_m = (uint64_t)(expect_hits * 0.03 * boost / shrink) + (uint64_t)(4194304 / shrink) + 64;
     uint64_t cap_l = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     uint64_t cap_c = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    uint64_t cap_w = (uint64_t)(expect_hits * 0.05 * boost / shrink) + (uint64_t)(16777216 / shrink) + 64;  // ~1.7 % on random sequence
+    // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
+    uint64_t cap_w = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     ExtCounters c;
     float ms_heavy = 0, ms_tails = 0, ms_walk = 0;
     for (int attempt = 0;; attempt++) {
         if ((rc = fkey.reserve(cap_f * 8)) || (rc = fprev.reserve(cap_f * 4)) || (rc = medq.reserve(cap_m * 8)) ||
             (rc = medu.reserve(cap_m * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
             (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp))) ||
-            (rc = hsp_unit.reserve(cap_c * 4)) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8)) || (rc = walku.reserve(v1 ? 4 : cap_w * 4)))
+            (rc = hsp_unit.reserve(cap_c * 4)) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8 * 8)))
             return rc;
         q.ctr = (ExtCounters *)ctr.p;
         q.cand = (Cand *)cand.p; q.fkey = (uint64_t *)fkey.p; q.fprev = (uint32_t *)fprev.p;
         q.medq = (uint2 *)medq.p; q.medu = (uint32_t *)medu.p; q.longq = (uint2 *)longq.p; q.longu = (uint32_t *)longu.p;
+        q.bigcand = (unsigned long long *)bigcand.p; q.bigacc = (unsigned long long *)bigacc.p;
         q.unit_hits = (unsigned long long *)unit_hits.p;
         q.tile_hits = (unsigned long long *)tile_hits.p;
-        q.walkq = (uint2 *)walkq.p; q.walku = (uint32_t *)walku.p;
+        q.walkq = (uint2 *)walkq.p;
         q.cand_cap = cap_c; q.follow_cap = cap_f; q.med_cap = cap_m; q.long_cap = cap_l; q.walk_cap = cap_w;
         const UnitDesc *d_units = (const UnitDesc *)units.p;
         HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(ExtCounters), st));
         HIP_TRY(hipMemsetAsync(unit_hits.p, 0, (size_t)nunits * 8, st));
         HIP_TRY(hipMemsetAsync(nsel.p, 0, 16, st));
+        HIP_TRY(hipMemsetAsync(bigacc.p, 0, (size_t)ENT_BIGCAP * 5 * 8, st));
         HIP_TRY(hipEventRecord(ev[0], st));
         // the main diagonals of the self units: one wavefront each, beside the heavy kernels
         if (!h_selfs.empty()) {
@@ -588,7 +672,18 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
             const UnitWork &w = work[u];
             if (!w.ti.n || !w.qi.n) continue;
             if (!v1) {
+                // K34, then the hits it could not dismiss (3-4 % on random sequence, most of them false alarms of its
+                // cheap filter) through the sharp filter and the exact walk of round 1's fast kernel, then the queue
+                // is empty again for the next unit: three stream-ordered launches, nothing read back
                 if ((rc = launch_fused_unit(w, u, q, p, tab, st))) return rc;
+                const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
+                const unsigned long long *d_n = q.ctr->nwalk;
+#define K4_QUEUE(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3(1024), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)q.walkq, q.walk_cap, \
+                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, 0, d_n)
+                if (slim) K4_QUEUE(9);
+                else K4_QUEUE(5);
+#undef K4_QUEUE
+                hipLaunchKernelGGL(k4_queue_reset, dim3(1), dim3(1), 0, st, q.ctr, q.walk_cap);
             } else {
                 // A/B path: materialise the hits (exact count: one round trip per unit), then the round-1 fast kernel
                 uint64_t nh = 0;
@@ -598,7 +693,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
                 const int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 0;
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)hits.p, nh, \
-                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, (int)w.d.same)
+                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, (int)w.d.same, (const unsigned long long *)nullptr)
                 if (variant == 1) K4_LAUNCH(1);
                 else if (variant == 5 || !slim) K4_LAUNCH(5);
                 else K4_LAUNCH(9);
@@ -608,8 +703,6 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         if (!v1) launch_sum_hits(q, nunits, st);
         HIP_TRY(hipEventRecord(ev[1], st));
         // ---- tails, once per batch
-        if (!v1)
-            hipLaunchKernelGGL(k4_walk_queue, dim3(2048), dim3(FAST_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh, p->transitions, tab);
         HIP_TRY(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k4_extend_generic, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh,
                            p->transitions, tab);
@@ -617,7 +710,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         hipLaunchKernelGGL(k4_extend_long, dim3(256), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh, p->transitions);
         HIP_TRY(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // round trip 1: follower count (sizes the sort), overflow check
-        bool over = c.nfollow > cap_f || c.nmed > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk > cap_w;
+        bool over = c.nfollow > cap_f || c.nmed > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > cap_w;
         if (!over && c.nfollow) {
             const uint64_t nf = c.nfollow;
             if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
@@ -645,6 +738,9 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         if (!over) {
             hipLaunchKernelGGL(k4_entropy, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, p->hspthresh, p->entropy,
                                (mimeo_hsp *)hsps.p, (uint32_t *)hsp_unit.p);
+            hipLaunchKernelGGL(k4_entropy_big, dim3(128, 16), dim3(256), 0, st, d_units, q);
+            hipLaunchKernelGGL(k4_entropy_big_finish, dim3(16), dim3(256), 0, st, q, p->hspthresh, p->entropy, (mimeo_hsp *)hsps.p,
+                               (uint32_t *)hsp_unit.p);
             HIP_TRY(hipEventRecord(ev[2], st));
             HIP_TRY(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));   // round trip 2: HSP count; the resolution may have added candidates
@@ -656,7 +752,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
                     c.dbg[0], c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7]);
         if (getenv("MIMEO_K4_STATS"))
             fprintf(stderr, "[k4] units %u walk queue %llu walked %llu generic %llu long %llu followers %llu candidates %llu hsps %llu%s\n", nunits,
-                    c.nwalk, c.nwalked, c.nmed, c.nlong, c.nfollow, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
+                    c.nwalk_total, c.nwalked, c.nmed, c.nlong, c.nfollow, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
         if (!over) {
             float a = 0, b = 0, w = 0;
             HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
@@ -673,7 +769,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         cap_m = std::max<uint64_t>(cap_m, c.nmed + c.nmed / 2 + 1024);
         cap_l = std::max<uint64_t>(cap_l, c.nlong + c.nlong / 2 + 1024);
         cap_c = std::max<uint64_t>(cap_c, 2 * c.ncand + 65536);
-        cap_w = std::max<uint64_t>(cap_w, c.nwalk + c.nwalk / 8 + 1024);
+        cap_w = std::max<uint64_t>(cap_w, c.nwalk_over + c.nwalk_over / 4 + 1024);
         if (stats) stats->reruns++;
     }
     h_unit_hits.resize(nunits);
@@ -682,7 +778,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     if (expect_hits > 1e6) {
         const double e = expect_hits;
         const double r = std::max({(double)c.nfollow / (0.02 * e), (double)c.nmed / (0.03 * e), (double)c.nlong / (0.002 * e),
-                                   (double)c.ncand / (0.002 * e), (double)c.nwalk / (0.05 * e)});
+                                   (double)c.ncand / (0.002 * e), (double)c.nwalk_total / (0.12 * e)});
         boost = std::min(64.0, std::max(boost, 1.5 * r));
     }
     if (stats) {
@@ -695,7 +791,8 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
             stats->scan_bytes_kernel += 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 52ull * ((uint64_t)work[u].ti.n + work[u].qi.n);
             if (work[u].ti.n && work[u].qi.n) stats->heavy_launches++;
         }
-        stats->walked += v1 ? c.nwalked : c.nwalk;
+        stats->walked += c.nwalked;
+        stats->walk_queue += c.nwalk_total;
         stats->ms_walk += ms_walk;
         stats->followers += c.nfollow;
         stats->candidates += c.ncand;

@@ -88,3 +88,23 @@ run('exact16  C12+tv', L16, R16, C12, True)
 run('mixed    C10 no tv', Lmix, Rmix, C10, False)
 run('loose16  C10 no tv', L16, R16, C10, False, exact=False)
 run('loose mixed C10 no tv', Lmix, Rmix, C10, False, exact=False)
+
+print()
+def cost(nl, nr, ncare, use_tv, exact, ngroups):
+    return 17 + ngroups * ncare * (6 if use_tv else 4) + (nl + nr) * (25 if exact else 15)
+def run2(tag, Lb, Rb, care, use_tv, exact):
+    ls, lub, lat = bounds(Lb, exact)
+    rs, rub, _ = bounds(Rb, exact)
+    nsteps = sum(len(x) for x in Lb)
+    al = alarm(care, use_tv)[:, :nsteps]
+    ends = np.cumsum([len(x) for x in Lb])
+    reach = np.where(lat < 99, ends[np.minimum(lat, len(Lb) - 1)], nsteps)
+    veto = (al & (np.arange(nsteps)[None, :] < reach[:, None])).any(1)
+    need = ~(ls & rs & (lub + rub < TH) & ~veto)
+    c = cost(len(Lb), len(Rb), len(care), use_tv, exact, (nsteps + 31) // 32)
+    print('%-40s pass %6.3f%%  filter %3d + walks %5.1f = %5.1f instr / batch' % (tag, 100 * need.mean(), c, 600 * need.mean(), c + 600 * need.mean()))
+for exact in (True, False):
+    for nl, nr in ((6, 4), (4, 4), (4, 3), (6, 3), (5, 3)):
+        for care, cn in ((C8, 'C8'), (C10, 'C10'), (C12, 'C12')):
+            for tvf in (False, True):
+                run2('%s L%d R%d %s%s' % ('exact' if exact else 'loose', nl * 16, nr * 16, cn, '+tv' if tvf else ''), L16[:nl], R16[:nr], care, tvf, exact)
