@@ -373,7 +373,7 @@ __device__ __forceinline__ FilterMasks filter_left(const Frame &F, uint32_t bt, 
     uint32_t ones = 0, twos = 0, tv = 0;
 #pragma unroll
     for (int c = 0; c < SEED_LEN; c++) {
-        if (!((CARE8 >> c) & 1u)) continue;
+        if (!((CARE19 >> c) & 1u)) continue;
         const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
         twos |= ones & v;
         ones |= v;
@@ -503,8 +503,9 @@ __device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const
 // ---- per-wavefront staging of the records the exact walks produce ---------------------------------------
 // One global atomic serves >= 64 records instead of one per wavefront iteration (same-address atomics serialise
 // at ~12-15 ns each).  s_med / s_fk / s_fp (and s_cd when STAGE_CAND) are QCAP-entry LDS arrays private to the
-// wavefront; the fill levels are wave-uniform registers of the caller.  A queue is flushed when the new records
-// would not fit (QCAP = 64 = the most one batch can add); `final` flushes what is left.  Follower records are
+// wavefront (CAP entries for the frequent kinds, generic-walk hits and followers); the fill levels are wave-uniform
+// registers of the caller.  A queue is flushed when the new records would not fit (a batch adds at most 64); `final`
+// flushes what is left.  Follower records are
 // staged as (diagonal + Q.len) << 32 | seed end and get their batch key (unit, bit widths) at the flush.
 struct WaveFill { uint32_t n_med, n_fol, n_cd; };
 
@@ -512,7 +513,7 @@ __device__ __forceinline__ uint64_t batch_key(const ExtQueues &q, uint32_t unit,
     return ((uint64_t)unit << (q.dbits + q.ebits)) | ((staged >> 32) << q.ebits) | (staged & 0xFFFFFFFFull);
 }
 
-template <bool STAGE_CAND>
+template <bool STAGE_CAND, int CAP = QCAP>
 __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit, uint2 *s_med, uint64_t *s_fk, uint32_t *s_fp,
                                               Cand *s_cd, WaveFill &f, bool q_med, uint2 h, bool q_fol, uint64_t r_fk,
                                               uint32_t r_fp, bool q_cd, Cand r_cd, bool final) {
@@ -521,12 +522,13 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
     uint64_t m = __ballot(q_med);
     if (m || (final && f.n_med)) {
         const uint32_t add = (uint32_t)__popcll(m);
-        if (f.n_med + add > (uint32_t)QCAP || (final && !m)) {
+        if (f.n_med + add > (uint32_t)CAP || (final && !m)) {
             __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&q.ctr->nmed, (unsigned long long)f.n_med);
             b = __shfl(b, 0);
-            if (lane < f.n_med && b + lane < q.med_cap) { q.medq[b + lane] = s_med[lane]; q.medu[b + lane] = unit; }
+            for (uint32_t i = lane; i < f.n_med; i += 64)
+                if (b + i < q.med_cap) { q.medq[b + i] = s_med[i]; q.medu[b + i] = unit; }
             f.n_med = 0;
             __builtin_amdgcn_wave_barrier();
         }
@@ -537,19 +539,21 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&q.ctr->nmed, (unsigned long long)f.n_med);
             b = __shfl(b, 0);
-            if (lane < f.n_med && b + lane < q.med_cap) { q.medq[b + lane] = s_med[lane]; q.medu[b + lane] = unit; }
+            for (uint32_t i = lane; i < f.n_med; i += 64)
+                if (b + i < q.med_cap) { q.medq[b + i] = s_med[i]; q.medu[b + i] = unit; }
             f.n_med = 0;
         }
     }
     m = __ballot(q_fol);
     if (m || (final && f.n_fol)) {
         const uint32_t add = (uint32_t)__popcll(m);
-        if (f.n_fol + add > (uint32_t)QCAP || (final && !m)) {
+        if (f.n_fol + add > (uint32_t)CAP || (final && !m)) {
             __builtin_amdgcn_wave_barrier();
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&q.ctr->nfollow, (unsigned long long)f.n_fol);
             b = __shfl(b, 0);
-            if (lane < f.n_fol && b + lane < q.follow_cap) { q.fkey[b + lane] = batch_key(q, unit, s_fk[lane]); q.fprev[b + lane] = s_fp[lane]; }
+            for (uint32_t i = lane; i < f.n_fol; i += 64)
+                if (b + i < q.follow_cap) { q.fkey[b + i] = batch_key(q, unit, s_fk[i]); q.fprev[b + i] = s_fp[i]; }
             f.n_fol = 0;
             __builtin_amdgcn_wave_barrier();
         }
@@ -560,7 +564,8 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&q.ctr->nfollow, (unsigned long long)f.n_fol);
             b = __shfl(b, 0);
-            if (lane < f.n_fol && b + lane < q.follow_cap) { q.fkey[b + lane] = batch_key(q, unit, s_fk[lane]); q.fprev[b + lane] = s_fp[lane]; }
+            for (uint32_t i = lane; i < f.n_fol; i += 64)
+                if (b + i < q.follow_cap) { q.fkey[b + i] = batch_key(q, unit, s_fk[i]); q.fprev[b + i] = s_fp[i]; }
             f.n_fol = 0;
         }
     }

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
                                                               const uint32_t *__restrict__ group_tab, ExtQueues q, uint32_t unit,
                                                               int skip_diag0, const unsigned long long *__restrict__ nhits_dev) {
     constexpr bool FILTER = VARIANT == 5 || VARIANT == 9;
+    constexpr int SCAP = 256;   // staged generic-walk hits / followers per wavefront: one same-address atomic per 256 records
     // nhits_dev: the hits are the walk queue of this unit, filled by K34 just before on the same stream: eight shards of
     // capacity `nhits` each, the counts on the device.  sh_end[r] = hits in shards 0 .. r.
     uint64_t sh_end[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         nhits = acc;
     }
     __shared__ uint32_t tab[GROUP_TAB];
-    __shared__ uint2 s_med[FAST_THREADS / 64][QCAP];
-    __shared__ uint64_t s_fk[FAST_THREADS / 64][QCAP];
-    __shared__ uint32_t s_fp[FAST_THREADS / 64][QCAP];
+    __shared__ uint2 s_med[FAST_THREADS / 64][SCAP];
+    __shared__ uint64_t s_fk[FAST_THREADS / 64][SCAP];
+    __shared__ uint32_t s_fp[FAST_THREADS / 64][SCAP];
     __shared__ Cand s_cd[FAST_THREADS / 64][QCAP];
     __shared__ uint2 s_walk[FILTER ? FAST_THREADS / 64 : 1][QCAP];  // hits that passed the pre-filter, per wavefront
     for (int i = threadIdx.x; i < GROUP_TAB; i += FAST_THREADS) tab[i] = group_tab[i];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
         uint32_t r_fp = 0;
         Cand r_cd{0, 0, 0, 0, 0};
         if (active) walk_hit<1>(tab, T, Q, h, xdrop, hspthresh, transitions, q_med, q_fol, q_cd, r_fk, r_fp, r_cd);
-        stage_records<true>(q, unit, s_med[wv], s_fk[wv], s_fp[wv], s_cd[wv], fill, q_med, h, q_fol, r_fk, r_fp, q_cd, r_cd, final);
+        stage_records<true, SCAP>(q, unit, s_med[wv], s_fk[wv], s_fp[wv], s_cd[wv], fill, q_med, h, q_fol, r_fk, r_fp, q_cd, r_cd, final);
     };
 
     const uint64_t stride = (uint64_t)gridDim.x * FAST_THREADS;
@@ -678,7 +679,8 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
                 if ((rc = launch_fused_unit(w, u, q, p, tab, st))) return rc;
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
                 const unsigned long long *d_n = q.ctr->nwalk;
-#define K4_QUEUE(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3(1024), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)q.walkq, q.walk_cap, \
+                static const uint32_t qblocks = getenv("MIMEO_QW_BLOCKS") ? (uint32_t)atoi(getenv("MIMEO_QW_BLOCKS")) : 256u;
+#define K4_QUEUE(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3(qblocks), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)q.walkq, q.walk_cap, \
                            p->xdrop, p->hspthresh, p->transitions, tab, q, u, 0, d_n)
                 if (slim) K4_QUEUE(9);
                 else K4_QUEUE(5);
