@@ -3,7 +3,7 @@
 
 Default workload = the configuration BASELINE.json's metric is quoted on: C4, `mimeo self` on a 1 Gbp
 synthetic genome (100 scaffolds x 10 Mbp, 5 % planted repeats, seed 1000), --minIdt 80 --minLen 100
---minCov 3.  It fits one GPU (packed genome 1 GB + 21 GB of seed indexes in 288 GB).
+--minCov 3.  It fits one GPU (packed genome 1.5 GB + 117 GB of seed indexes with their seed frames, in 288 GB).
 
 A "step" (row mode, workloads c4 / c4small) = one TARGET scaffold per rank through the whole hot path:
 the seed indexes of that scaffold are (re)built (both strands), the scaffold is aligned as target against
@@ -133,28 +133,53 @@ def cpu_baseline_job(names, seqs, self_pair, cross_pair):
     return out
 
 
-def cpu_baseline_rows(seqs, slice_bp=2_000_000):
-    """Row mode (C4): a whole 10 Mbp x 10 Mbp pair takes the oracle about a minute, so the bounded sample
-    is target scaffold 0 against the first `slice_bp` bases of scaffold 1 (both strands); seed hits, and
-    with them the time, grow with Lt x Lq, so one ordered pair costs Lq/slice_bp times that and the job
-    S^2 pairs (the S self pairs are priced as cross pairs)."""
+def host_description():
+    """core count and CPU model of the box the baseline ran on (recorded next to every number)"""
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'cpu_model': model, 'cpus_online': os.cpu_count(), 'cpus_allowed': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None}
+
+
+def cpu_baseline_rows(seqs, samples=32, slice_bp=400_000, seed=8):
+    """Row mode (C4), SURVEY §8d: `samples` seeded-random (target scaffold, query scaffold) pairs, the oracle built
+    -O3 -march=native on this box, run on all host cores at once (one pair per thread) and, for the like-for-like
+    figure of the reference's serial script, the per-pair cost of one core.  A whole 10 Mbp x 10 Mbp pair takes the
+    oracle about a minute, so a sample aligns the whole target against a random `slice_bp` window of the query, both
+    strands; seed hits — and with them the time — grow with Lt x Lq, so a pair costs Lq / slice_bp samples."""
+    from oracle import oracle as O
+    native = O.use_native_build()
+    rng = np.random.Generator(np.random.PCG64(seed))
     S, L = len(seqs), len(seqs[0])
     sl = min(slice_bp, L)
-    t_buf = seqs[0].tobytes()
-    one = cpu_oracle_times([(t_buf, seqs[1][:sl].tobytes())])
-    total_s = one * (L / sl) * S * S
-    total_bp = S * L
-    out = {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
-           'sample': 'scaffold 0 (%.1f Mbp) x first %.1f Mbp of scaffold 1, both strands: %.1f s; whole job (%d ordered pairs) '
-                     'extrapolated as t * (Lq / slice) * S^2 = %.0f s' % (L / 1e6, sl / 1e6, one, S * S, total_s)}
+    jobs = []
+    for _ in range(samples):
+        t, q = int(rng.integers(0, S)), int(rng.integers(0, S))
+        o = int(rng.integers(0, L - sl + 1))
+        jobs.append((seqs[t].tobytes(), seqs[q][o:o + sl].tobytes()))
     cores = host_cores()
-    if cores > 1:
-        jobs = [(t_buf, seqs[1 + k % (S - 1)][(k // (S - 1)) * sl:(k // (S - 1) + 1) * sl].tobytes()) for k in range(cores)]
-        wall = cpu_oracle_times(jobs, threads=cores)
-        mt_s = (wall / cores) * (L / sl) * S * S
-        out['allcores'] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': cores, 'kind': 'port',
-                           'sample': '%d such slices run concurrently on %d threads in %.1f s; whole job extrapolated to %.0f s'
-                                     % (cores, cores, wall, mt_s)}
+    wall_mt = cpu_oracle_times(jobs, threads=cores)
+    one = cpu_oracle_times(jobs[:2]) / 2                       # one core, two of the samples
+    pairs = S * S
+    per_pair_1 = one * (L / sl)
+    total_1 = per_pair_1 * pairs
+    total_mt = (wall_mt / samples) * (L / sl) * pairs
+    total_bp = S * L
+    host = host_description()
+    out = {'value': total_bp / 1e9 / total_1, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
+           'sample': '2 of the %d sampled (scaffold, %.1f Mbp query window) jobs on one core: %.1f s each; a 10 Mbp x 10 Mbp pair = %.0f such '
+                     'windows, the job %d ordered pairs: %.0f s extrapolated; oracle/ built %s'
+                     % (samples, sl / 1e6, one, L / sl, pairs, total_1, '-O3 -march=native on this box' if native else '-O3 (portable build)'),
+           'host': host}
+    out['allcores'] = {'value': total_bp / 1e9 / total_mt, 'unit': 'Gbp-aligned/s', 'cores': cores, 'kind': 'port',
+                       'sample': '%d seeded-random (target, query window) jobs on %d threads in %.1f s; whole job extrapolated to %.0f s'
+                                 % (samples, cores, wall_mt, total_mt)}
     return out
 
 
@@ -177,17 +202,34 @@ def reference_tools_check():
 
 
 def pmc_traffic(workload):
-    """HBM bytes per seed-scan launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 correction, calibrated on k3_join_count; profiles/r01_pmc_seed_scan.json)."""
-    key = {'c2': 'c2', 'c4': 'c4'}.get(workload)
+    """HBM bytes per launch of the seed-scan kernel K34 from the committed rocprofv3 PMC passes
+    (profiles/r02_pmc_seed_scan.json, scripts/gpu_pmc_traffic.sh): FETCH_SIZE doubled (gfx950 tallies the 128-byte
+    requests of wide coalesced reads as 64 bytes: MI355X_MICROARCH.md, HBM; calibrated in round 1 on a kernel of known
+    traffic) + WRITE_SIZE as is."""
+    key = {'c2': 'c2_unit', 'c4': 'c4_unit', 'c4job': 'c4_unit'}.get(workload)
     if key is None:
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_seed_scan.json')) as f:
-            d = json.load(f)['k3_join_fill']
-        return d['corrected_bytes_per_launch_cross_unit' if key == 'c2' else 'corrected_bytes_per_launch_c4_unit']
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_seed_scan.json')) as f:
+            d = json.load(f)
+        return int(1024 * (2 * d[key + '_FETCH_SIZE_KB_per_launch']['k34_scan_extend'] + d[key + '_WRITE_SIZE_KB_per_launch']['k34_scan_extend']))
     except Exception:
         return None
+
+
+def standalone_seed_scan(engine, A, tq):
+    """Calibration OUTSIDE the timed region: the stand-alone seed scan of round 1 (K3 index join, materialises the hit
+    array; kept behind mimeo_seed_hits) on one unit of the workload, alone on the device — the seed scan's own
+    roofline fraction by the survey's byte model, next to the in-pipeline figure of the fused kernel."""
+    t, q = tq
+    hits = engine.seed_hits(A, t, A, q, 0)
+    st = engine.stats()
+    Lq = int(A.lengths[q])
+    b_alg = (Lq + 3) // 4 + 8 * 13 * max(0, Lq - 18) + 12 * int(hits.size)
+    ms = st['ms_scan_fill']
+    return {'kernel': 'k3_join_fill (stand-alone seed scan: hits written to HBM)', 'avg_launch_ms': ms,
+            'algorithmic_bytes_per_launch': b_alg, 'achieved': b_alg / (ms / 1e3) / 1e9 if ms > 0 else None,
+            'frac': b_alg / (ms / 1e3) / 8e12 if ms > 0 else None}
 
 
 def main():
@@ -291,11 +333,18 @@ def main():
     dt = dist.max_float(time.time() - t0)
     ms_per_step = 1000.0 * dt / max(1, args.steps)
 
+    standalone = None
+    if dist.rank == 0 and B is None and nscaf > 1:
+        try:
+            standalone = standalone_seed_scan(engine, A, (0, 1))
+        except Exception as e:   # the calibration must never cost the bench line
+            standalone = {'error': repr(e)}
     if dist.rank == 0:
         launches = max(1, agg['scan_launches'])
         t_fill = agg['ms_scan_fill'] / 1e3 / launches          # s per seed-scan (fill) launch, HIP events
         b_alg = agg['scan_bytes_algorithmic'] / launches        # SURVEY §8(d) B_scan per launch
         achieved = b_alg / t_fill / 1e9 if t_fill > 0 else 0.0
+        traffic = pmc_traffic(args.workload)
         scaf_mbp = total_bp / nscaf / 1e6
         if kind == 'row':
             # target bases completed by all ranks per second; S/N such steps are the whole job
@@ -319,12 +368,19 @@ def main():
                                    % (args.workload.upper(), mode, total_bp // 1_000_000, '' if B is None else ' x2 (A, B)', nscaf,
                                       scaf_mbp, seed if B is None else '%d/%d' % (seed, seed_b), what),
                        'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': par},
-            'roofline': {'kernel': 'k3_join_fill (seed scan)', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': pmc_traffic(args.workload), 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_seed_scan.json)',
+            'roofline': {'kernel': 'k34_scan_extend (seed scan fused with the gap-free pre-filter; one launch per (target, query, strand) unit)',
+                         'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
+                         'traffic_frac': (traffic / t_fill / 8e12) if (traffic and t_fill > 0) else None,
                          'kernel_bytes_per_launch': agg['scan_bytes_kernel'] / launches,
-                         'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches)},
+                         'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches),
+                         'note': 'achieved = SURVEY 8(d) B_scan per unit / HIP-event duration of the launch.  The fused kernel never writes the hit '
+                                 'array the byte model charges for, and it is bound by VALU issue of the pre-filter (popcounts, funnel shifts), not '
+                                 'by HBM: traffic_frac is what it really moves; frac_standalone is the seed scan alone.',
+                         'frac_standalone': standalone},
             'stage_ms_per_step_rank0': {k: round(agg[k] / max(1, args.steps), 3) for k in ('ms_index', 'ms_scan', 'ms_scan_fill', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_total')},
-            'counts_per_step_rank0': {k: int(agg[k] // max(1, args.steps)) for k in ('seed_hits', 'hsps', 'chained_hsps', 'alignments')},
+            'stage_note': 'ms_scan = heavy phase (K34 + the walk-queue kernel per unit), ms_scan_fill = the K34 launches alone, ms_extend = tails once per batch; K34 timed region includes nothing else: inputs (packed genome, seed indexes of the other scaffolds) are resident in HBM, the H2D of the genome (1 GB, ~16 ms + 6 ms K1 per 50 s job) is outside',
+            'counts_per_step_rank0': {k: int(agg[k] // max(1, args.steps)) for k in ('seed_hits', 'walked_hits', 'followers', 'hsps', 'chained_hsps', 'alignments', 'batches', 'queue_reruns')},
             'result': ({'records_kept': n_aln, 'regions': n_reg} if kind == 'row' else {'alignments': int(alns.size), 'regions': int(regions.size)}),
         }
         if kind == 'row':

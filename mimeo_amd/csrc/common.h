@@ -175,7 +175,7 @@ struct UnitWork {  // host side: a unit with the seed indexes its heavy kernel r
 struct ExtStats {
     uint64_t seed_hits = 0, walked = 0, walk_queue = 0, followers = 0, candidates = 0, reruns = 0;
     uint64_t scan_bytes_algorithmic = 0, scan_bytes_kernel = 0, heavy_launches = 0;
-    float ms_heavy = 0, ms_walk = 0, ms_tails = 0;  // ms_walk: the exact walks of the walk queue (part of ms_tails)
+    float ms_heavy = 0, ms_k34 = 0, ms_walk = 0, ms_tails = 0;  // ms_k34: the K34 launches alone (event pair per launch)  // ms_walk: the exact walks of the walk queue (part of ms_tails)
 };
 // The extension stage of one batch: heavy kernel per unit (K34 fused seed scan + pre-filter + exact walks; or, for
 // A/B checks, the stand-alone K3 join + K4 fast kernel of round 1) appending to batch-wide queues, then the tails ONCE
@@ -186,6 +186,7 @@ struct ExtBatch {
         hsp_unit, unit_hits, tile_hits, selfs, hits, bigcand, bigacc;
     JoinCtx jc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> kev;     // an event pair per unit around its K34 launch
     hipStream_t side = nullptr;      // k4_diag0 of the self units runs beside the heavy kernels
     hipEvent_t side_done = nullptr;
     std::vector<unsigned long long> h_unit_hits;

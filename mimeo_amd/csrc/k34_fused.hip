@@ -123,7 +123,7 @@ struct FusedCfg {
 };
 
 template <int THREADS, uint32_t QSEG>
-__global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
+__global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3 : (QSEG > 1024 ? 2 : 4)))) void k34_scan_extend(FusedArgs A) {
     constexpr int WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *sQ = reinterpret_cast<uint32_t *>(smem);                                  // TILE_WORDS + 4
@@ -332,6 +332,8 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
     const uint32_t avg = (uint32_t)(((uint64_t)w.qi.n + NTILE - 1) / NTILE);
     const bool big = cfg ? cfg == 1 : false;  // measured: two 512-thread workgroups per CU win on 10 Mbp tiles too (1.30 vs 1.62 ms per C4 unit)
     (void)avg;
+    if (cfg == 3) return launch_cfg<768, 2560>(A, st);
+    if (cfg == 4) return launch_cfg<512, 2560>(A, st);
     return big ? launch_cfg<1024, 2048>(A, st) : launch_cfg<512, 1024>(A, st);
 }
 

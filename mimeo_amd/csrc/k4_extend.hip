@@ -566,6 +566,8 @@ void ExtBatch::release() {
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    for (auto &e : kev) (void)hipEventDestroy(e);
+    kev.clear();
     if (side_done) { (void)hipEventDestroy(side_done); side_done = nullptr; }
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
 }
@@ -640,7 +642,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
     uint64_t cap_w = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     ExtCounters c;
-    float ms_heavy = 0, ms_tails = 0, ms_walk = 0;
+    float ms_heavy = 0, ms_tails = 0, ms_walk = 0, ms_k34 = 0;
     for (int attempt = 0;; attempt++) {
         if ((rc = fkey.reserve(cap_f * 8)) || (rc = fprev.reserve(cap_f * 4)) || (rc = medq.reserve(cap_m * 8)) ||
             (rc = medu.reserve(cap_m * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
@@ -676,7 +678,14 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
                 // K34, then the hits it could not dismiss (3-4 % on random sequence, most of them false alarms of its
                 // cheap filter) through the sharp filter and the exact walk of round 1's fast kernel, then the queue
                 // is empty again for the next unit: three stream-ordered launches, nothing read back
+                while (kev.size() < 2 * (size_t)(u + 1)) {   // an event pair per unit: the seed-scan kernel's own duration
+                    hipEvent_t e;
+                    HIP_TRY(hipEventCreate(&e));
+                    kev.push_back(e);
+                }
+                HIP_TRY(hipEventRecord(kev[2 * u], st));
                 if ((rc = launch_fused_unit(w, u, q, p, tab, st))) return rc;
+                HIP_TRY(hipEventRecord(kev[2 * u + 1], st));
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
                 const unsigned long long *d_n = q.ctr->nwalk;
                 static const uint32_t qblocks = getenv("MIMEO_QW_BLOCKS") ? (uint32_t)atoi(getenv("MIMEO_QW_BLOCKS")) : 256u;
@@ -763,6 +772,13 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
             ms_heavy += a;
             ms_tails += b;
             ms_walk += w;
+            if (!v1)
+                for (uint32_t u = 0; u < nunits; u++)
+                    if (work[u].ti.n && work[u].qi.n) {
+                        float t = 0;
+                        HIP_TRY(hipEventElapsedTime(&t, kev[2 * u], kev[2 * u + 1]));
+                        ms_k34 += t;
+                    }
             break;
         }
         if (attempt >= 2) { set_error("extension queues overflowed twice in a row"); return MIMEO_ERR_LIMIT; }
@@ -796,6 +812,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         stats->walked += c.nwalked;
         stats->walk_queue += c.nwalk_total;
         stats->ms_walk += ms_walk;
+        stats->ms_k34 += v1 ? ms_heavy : ms_k34;
         stats->followers += c.nfollow;
         stats->candidates += c.ncand;
         stats->ms_heavy += ms_heavy;

@@ -300,7 +300,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     g_stats.queue_reruns = est.reruns;
     g_stats.ms_index = ms_index;
     g_stats.ms_scan = est.ms_heavy;
-    g_stats.ms_scan_fill = est.ms_heavy;
+    g_stats.ms_scan_fill = est.ms_k34;
     g_stats.ms_extend = est.ms_tails;
     g_stats.ms_chain = ms_chain;
     g_stats.ms_gapped = ms_gapped;

@@ -34,12 +34,26 @@ def build():
     subprocess.check_call(['make', '-s', '-C', HERE])
 
 
-def lib():
+def use_native_build():
+    """bench.py's cpu_baseline leg: rebuild with -O3 -march=native on the box that runs it and load
+    that library from now on; False (and the portable -O3 build stays) when no compiler is there."""
+    global _lib
+    native = os.path.join(HERE, '_build', 'libmimeo_oracle_native.so')
+    try:
+        subprocess.check_call(['make', '-s', '-C', HERE, 'native'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _lib = None
+    lib(native)
+    return True
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        if path is None and not os.path.exists(LIB):
             build()
-        _lib = C.CDLL(LIB)
+        _lib = C.CDLL(path or LIB)
         _lib.orc_free.argtypes = [C.c_void_p]
         for fn in (_lib.orc_seed_hits, _lib.orc_ungapped_hsps):
             fn.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(Params),
