@@ -183,7 +183,7 @@ struct ExtStats {
 // segment resolution, entropy.  Two host synchronisations per batch.  Leaves nhsp HSPs in hsps / hsp_unit (device).
 struct ExtBatch {
     DeviceBuf units, ctr, cand, fkey, fkey2, fprev, fprev2, medq, medu, longq, longu, walkq, flags, segs, tmp, nsel, bigseg, hsps,
-        hsp_unit, unit_hits, tile_hits, selfs, hits, bigcand, bigacc;
+        hsp_unit, unit_hits, tile_hits, selfs, hits, bigcand, bigacc, heavy;
     JoinCtx jc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> kev;     // an event pair per unit around its K34 launch

@@ -29,6 +29,9 @@ namespace mimeo {
 constexpr uint32_t TCH = 64;      // target entries per wavefront and chunk: one per lane
 constexpr uint32_t DQ = 256;      // pair descriptors per wavefront and round
 constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CARE19
+constexpr unsigned long long HEAVY_HITS = 262144;   // hits of a tile beyond which it is split (a tile of a 10 Mbp x 10 Mbp unit averages 19 000)
+constexpr uint32_t HEAVY_MAX = 64;     // listed tiles per unit = grid of the split pass (further ones are done unsplit by the first pass)
+constexpr uint32_t HEAVY_SPLIT = 8, HEAVY_QSPLIT = 8;   // ... over 8 shares of its target chunks x 8 shares of its query segments
 
 struct FusedArgs {
     IndexView T, Q;
@@ -38,6 +41,8 @@ struct FusedArgs {
     uint32_t unit, same;
     uint32_t tsoft;        // the target has a seed-validity plane of its own (soft-masked bases): no frame walks
     int xdrop, hspthresh, transitions;
+    uint32_t heavy_base;   // heavy pass: first listed tile of this launch
+    uint32_t heavy_pass;   // 0: every tile but the heavy ones (they are listed); 1: the listed tiles, each split over gridDim.y workgroups
     uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on
 };
 
@@ -133,7 +138,16 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
     uint8_t *sQN = reinterpret_cast<uint8_t *>(s_walk_all + WAVES * 64);                 // QSEG
     unsigned long long *s_total = reinterpret_cast<unsigned long long *>(sQN + QSEG);
 
-    const uint32_t tile = blockIdx.x;
+    // A tile with far more hits than the average (a microsatellite's seed words: thousands of entries of ONE key on both
+    // sides, 10^7-10^8 hits in one tile) is not worked off by one workgroup while the chip waits: the first pass lists it,
+    // the second pass (grid = listed tiles x HEAVY_SPLIT x HEAVY_QSPLIT) cuts its target chunks and its query segments
+    // over that many workgroups.
+    uint32_t tile = blockIdx.x;
+    if (A.heavy_pass) {
+        const uint32_t nlist = (uint32_t)min((unsigned long long)HEAVY_MAX, A.q.ctr->nheavy);
+        if (blockIdx.x + A.heavy_base >= nlist) return;
+        tile = A.q.heavy[blockIdx.x + A.heavy_base];
+    }
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t t0 = A.T.off[(size_t)tile * TILE_WORDS], nT = A.T.off[(size_t)tile * TILE_WORDS + TILE_WORDS] - t0;
@@ -146,16 +160,55 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
     __syncthreads();
     const uint32_t q0 = sQ[0], nQ = sQ[TILE_WORDS] - q0;
     if (!nT || !nQ) {
-        if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
+        if (threadIdx.x == 0 && !A.heavy_pass) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
         return;
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] -= q0;   // offsets relative to the tile's first query entry
     const bool single = nQ <= QSEG;   // the whole query tile in one segment: no clipping of the neighbour ranges
+    if (A.heavy_pass && blockIdx.z * QSEG >= nQ) return;   // no query segment for this share (uniform: before any further barrier)
+    if (!A.heavy_pass) {
+        // The tile's hit count up front (K3's counting pass, per tile: the target offsets pass through the frame area of
+        // LDS once): it is the statistic, and a tile with far more hits than the average is left to the split pass.
+        __syncthreads();
+        uint32_t *sT = reinterpret_cast<uint32_t *>(sQF);
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(A.T.off + (size_t)tile * TILE_WORDS);
+            uint4 *dst = reinterpret_cast<uint4 *>(sT);
+            for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += THREADS) dst[k] = src[k];
+            if (threadIdx.x == 0) sT[TILE_WORDS] = t0 + nT;
+        }
+        __syncthreads();
+        unsigned long long cnt = 0;
+        for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS) {
+            const uint32_t nt = sT[w + 1] - sT[w];
+            if (nt) {
+                uint32_t sum = sQ[w + 1] - sQ[w];
+                if (A.transitions)
+                    for (int j = 0; j < SEED_WEIGHT; j++) { const uint32_t w2 = w ^ (1u << j); sum += sQ[w2 + 1] - sQ[w2]; }
+                cnt += (unsigned long long)nt * sum;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0 && cnt) atomicAdd(s_total, cnt);
+        __syncthreads();
+        const unsigned long long tile_total = *s_total;
+        if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = tile_total;
+        if (tile_total > HEAVY_HITS) {
+            __shared__ unsigned long long s_slot;
+            if (threadIdx.x == 0) {
+                s_slot = atomicAdd(&A.q.ctr->nheavy, 1ull);
+                if (s_slot < HEAVY_MAX) A.q.heavy[s_slot] = tile;
+            }
+            __syncthreads();
+            if (s_slot < HEAVY_MAX) return;   // the split pass does this tile (beyond the list's capacity: this workgroup does, after all)
+        }
+        if (!tile_total) return;
+        __syncthreads();
+    }
     uint32_t *sD = sD_all + wv * DQ;
     uint2 *s_walk = s_walk_all + wv * 64;
     uint32_t n_walk = 0;
-    unsigned long long wave_hits = 0;
     const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
 
     // the pairs the filter passed on go to the batch's walk queue, 64 at a time (one atomic per flush)
@@ -170,14 +223,17 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
     };
 
     const uint32_t nchunks = (nT + TCH - 1) / TCH;
+    // chunks of this workgroup: every one (first pass), or those of my share of the tile (heavy pass)
+    const uint32_t ch_first = (A.heavy_pass ? blockIdx.y * WAVES : 0u) + wv, ch_step = (A.heavy_pass ? gridDim.y : 1u) * WAVES;
     // my first chunk's frames (one entry per lane): in flight while the first query segment is staged
     uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = nf0, nf2 = nf0;
     uint32_t npos = 0;
-    if (wv < nchunks) {
-        const uint32_t e = wv * TCH + lane;
+    if (ch_first < nchunks) {
+        const uint32_t e = ch_first * TCH + lane;
         if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
     }
-    for (uint32_t qs = 0; qs < nQ; qs += QSEG) {
+    const uint32_t qs_first = A.heavy_pass ? blockIdx.z * QSEG : 0u, qs_step = (A.heavy_pass ? gridDim.z : 1u) * QSEG;
+    for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
         const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
         __syncthreads();  // every wavefront is through with the previous segment
         {
@@ -190,13 +246,13 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
             }
         }
         __syncthreads();
-        for (uint32_t ch = wv; ch < nchunks; ch += WAVES) {
+        for (uint32_t ch = ch_first; ch < nchunks; ch += ch_step) {
             const uint32_t e0 = ch * TCH, ne = min(TCH, nT - e0);
             const uint4 f0 = nf0, f1 = nf1, f2 = nf2;
             const uint32_t mypos = npos;
             {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
-                uint32_t nx = ch + WAVES;
-                if (nx >= nchunks) nx = (qs + QSEG < nQ) ? wv : 0xFFFFFFFFu;
+                uint32_t nx = ch + ch_step;
+                if (nx >= nchunks) nx = (qs + qs_step < nQ) ? ch_first : 0xFFFFFFFFu;
                 if (nx != 0xFFFFFFFFu && nx != ch) {
                     const uint32_t e = nx * TCH + lane;
                     if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
@@ -230,7 +286,6 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
                 if (lane >= (uint32_t)o) inc += v;
             }
             const uint32_t tot = __shfl(inc, 63), st = inc - c;
-            wave_hits += tot;
             for (uint32_t rb = 0; rb < tot; rb += DQ) {
                 if (c && st < rb + DQ && st + c > rb) {
                     uint32_t acc = st;
@@ -283,9 +338,6 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
         }
     }
     if (n_walk) flush_walk(n_walk);
-    if (lane == 0) atomicAdd(s_total, wave_hits);
-    __syncthreads();
-    if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = *s_total;
 }
 
 // one workgroup per unit: unit_hits[u] = sum of its tile counts (once per batch)
@@ -305,6 +357,9 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st) {
     hipLaunchKernelGGL(k34_sum_hits, dim3(nunits), dim3(256), 0, st, (const unsigned long long *)q.tile_hits, q.unit_hits);
 }
 
+// The split pass is launched with a fixed grid: HEAVY_MAX listed tiles x HEAVY_SPLIT (2048 workgroups that exit at once
+// when no tile is heavy: a few microseconds per unit)
+static const dim3 HEAVY_GRID(HEAVY_MAX, HEAVY_SPLIT, HEAVY_QSPLIT);
 template <int THREADS, uint32_t QSEG>
 static int launch_cfg(const FusedArgs &A, hipStream_t st) {
     static bool attr_done = false;
@@ -315,6 +370,10 @@ static int launch_cfg(const FusedArgs &A, hipStream_t st) {
         attr_done = true;
     }
     hipLaunchKernelGGL((k34_scan_extend<THREADS, QSEG>), dim3(NTILE), dim3(THREADS), smem, st, A);
+    // the heavy tiles the first pass listed, each cut over HEAVY_SPLIT workgroups (workgroups beyond the list exit at once)
+    FusedArgs H = A;
+    H.heavy_pass = 1;
+    hipLaunchKernelGGL((k34_scan_extend<THREADS, QSEG>), dim3(HEAVY_GRID), dim3(THREADS), smem, st, H);
     return 0;
 }
 
@@ -325,6 +384,7 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
     A.tlen = w.d.T.len; A.qlen = w.d.Q.len; A.tsoft = w.d.T.svt != nullptr ? 1u : 0u;
     A.unit = unit; A.same = w.d.same;
     A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
+    A.heavy_pass = 0; A.heavy_base = 0;
     A.dbg = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
     // workgroup shape: one 1024-thread workgroup per CU with a 2048-entry query segment (most 10 Mbp x 10 Mbp tiles in
     // two passes), or two 512-thread workgroups per CU with 1024-entry segments (scaffolds up to ~5 Mbp: one pass)

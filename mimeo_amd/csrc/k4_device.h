@@ -19,6 +19,7 @@ struct ExtCounters {
     unsigned long long nwalk[8];   // entries of the walk queue of the current unit (K34 -> k4_extend_hits on the queue), in eight
                                    // shards (workgroup number mod 8, i.e. per XCD): 50 000 flushes per unit on ONE counter
                                    // would serialise at ~13 ns each
+    unsigned long long nheavy;     // tiles of the current unit that K34's first pass left to its split pass
     unsigned long long nbigcand;   // candidates longer than ENT_LONG columns: their entropy is counted by the whole grid
     unsigned long long nwalk_total, nwalk_over;  // ... summed over the batch; largest shard count that exceeded a shard's capacity
     unsigned long long dbg[8];  // development (MIMEO_K34_DEBUG & 8): why the pre-filter passed a hit on
@@ -43,6 +44,7 @@ struct ExtQueues {
     uint2 *medq, *longq;      // hits whose walk outlives the frame / LONG_WINDOWS windows
     uint32_t *medu, *longu;   // ... and their units
     uint2 *walkq;             // hits of the current unit that the pre-filter of K34 could not dismiss
+    uint32_t *heavy;                // ... their numbers
     unsigned long long *bigcand;    // indices of the long candidates (ENT_BIGCAP) and their accumulators: 5 per candidate
     unsigned long long *bigacc;     // ... matched A / C / G / T columns, raw score
     unsigned long long *unit_hits;  // seed hits per unit (statistics)

@@ -210,6 +210,7 @@ __global__ void k4_queue_reset(ExtCounters *ctr, uint64_t cap) {
         if (n > cap) ctr->nwalk_over = max(ctr->nwalk_over, n);
         ctr->nwalk[r] = 0;
     }
+    ctr->nheavy = 0;
 }
 
 // ---- long hits, one wavefront each ------------------------------------------------------------------------
@@ -562,7 +563,7 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
     for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc})
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -623,7 +624,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     int rc;
     if ((rc = units.reserve((size_t)nunits * sizeof(UnitDesc))) || (rc = ctr.reserve(sizeof(ExtCounters))) ||
         (rc = unit_hits.reserve((size_t)nunits * 8)) || (rc = nsel.reserve(16)) ||
-        (rc = tile_hits.reserve(v1 ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) ||
+        (rc = tile_hits.reserve(v1 ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) || (rc = heavy.reserve(4096 * 4)) ||
         (rc = bigacc.reserve((size_t)ENT_BIGCAP * 5 * 8)) ||
         (rc = selfs.reserve((h_selfs.size() + 1) * 4)))
         return rc;
@@ -652,6 +653,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         q.ctr = (ExtCounters *)ctr.p;
         q.cand = (Cand *)cand.p; q.fkey = (uint64_t *)fkey.p; q.fprev = (uint32_t *)fprev.p;
         q.medq = (uint2 *)medq.p; q.medu = (uint32_t *)medu.p; q.longq = (uint2 *)longq.p; q.longu = (uint32_t *)longu.p;
+        q.heavy = (uint32_t *)heavy.p;
         q.bigcand = (unsigned long long *)bigcand.p; q.bigacc = (unsigned long long *)bigacc.p;
         q.unit_hits = (unsigned long long *)unit_hits.p;
         q.tile_hits = (unsigned long long *)tile_hits.p;

@@ -190,18 +190,29 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
         if (tid == 0) s_m = n;
         __syncthreads();
     }
-    // 2. anchor order of the flagged HSPs (rank among flagged by anchor_less)
-    for (uint32_t i = tid; i < n; i += CH_THREADS) {
-        mimeo_hsp me = hs[b0 + i];
-        if (!(me.flags & 1u)) continue;
-        uint32_t rank = 0;
-        for (uint32_t k = 0; k < n; k++) {
-            const mimeo_hsp &o = hs[b0 + k];
-            if ((o.flags & 1u) && k != i && anchor_less(o, me)) rank++;
-        }
-        order[b0 + rank] = i;
-    }
+    // 2. the anchor order of the flagged HSPs is made by ONE stable device-wide sort behind this kernel (k5_rank_keys)
     if (tid == 0) G.nchain = s_m;
+}
+
+// Anchor order = (score descending, tstart, qstart, length) among the chained HSPs of a group.  The HSPs already lie in
+// (group, tstart, qstart, length) order, so one STABLE radix sort by (group, not chained, -score) leaves every group's
+// chained HSPs in anchor order at the front of its range (round 1 ranked each chained HSP against all HSPs of its
+// group: O(n m) per group, the larger part of the minute a 150 Mbp self unit spent in K5).
+__global__ void k5_rank_keys(const mimeo_hsp *__restrict__ hs, const uint64_t *__restrict__ gkey, uint64_t n, uint64_t *__restrict__ key,
+                             uint32_t *__restrict__ val) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t MAXS = (1ull << 40) - 1ull;
+    const int64_t sc = hs[i].score;
+    const uint64_t inv = MAXS - (uint64_t)(sc < 0 ? 0 : (sc > (int64_t)MAXS ? (int64_t)MAXS : sc));
+    key[i] = ((gkey[i] >> 32) << 41) | ((hs[i].flags & 1u) ? 0ull : (1ull << 40)) | inv;
+    val[i] = (uint32_t)i;
+}
+__global__ void k5_write_order(const uint32_t *__restrict__ val, const uint64_t *__restrict__ key, const Group *__restrict__ groups,
+                               uint64_t n, uint32_t *__restrict__ order) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    order[r] = val[r] - (uint32_t)groups[key[r] >> 41].hsp_begin;   // index inside the group
 }
 
 int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
@@ -229,6 +240,13 @@ int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, con
     hipLaunchKernelGGL(k5_gather, grd, blk, 0, st, d_hsps, (const uint32_t *)vA.p, nhsps, d_sorted);
     hipLaunchKernelGGL(k5_chain, dim3(ngroups), dim3(CH_THREADS), 0, st, d_groups, d_sorted, d_best,
                        d_cand, d_pred, d_order, do_chain);
+    // kB still holds the sorted (group, tstart) keys: anchor order by one stable sort over 54 key bits
+    hipLaunchKernelGGL(k5_rank_keys, grd, blk, 0, st, (const mimeo_hsp *)d_sorted, (const uint64_t *)kB.p, nhsps, (uint64_t *)kA.p,
+                       (uint32_t *)vB.p);
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t *)kA.p, (uint64_t *)kB.p, (uint32_t *)vB.p, (uint32_t *)vA.p,
+                                      (size_t)nhsps, 0, 64, st));
+    hipLaunchKernelGGL(k5_write_order, grd, blk, 0, st, (const uint32_t *)vA.p, (const uint64_t *)kB.p, (const Group *)d_groups, nhsps,
+                       d_order);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -167,3 +167,25 @@ def test_long_extension_beyond_packed_counts(eng):
     assert exp.size >= 1 and int((exp['tend'] - exp['tstart']).max()) > 280_000
     _cmp(got, exp, 'long', ordered=True)
     g.close()
+
+
+def test_chain_with_tens_of_thousands_of_hsps(eng):
+    """K5 at a size where its structure matters: ~7e4 HSPs in ONE unit (a low hspthresh on an 800 kbp pair makes
+    nearly every strong seed hit an HSP).  The chained subset — the alignments with gapped extension off — must equal
+    the oracle's O(n^2) chain, and the anchor order (one stable device-wide sort by group, chained, score) must be
+    the oracle's: score descending, then (tstart, qstart, length)."""
+    from oracle import oracle as O
+    names, seqs = synth_genome(66, 1_600_000, 2, repeat_frac=0.1, families=3, cons_len=(300, 3000), max_div=0.1)
+    g = eng.Genome(names, seqs)
+    got = eng.align_pair(g, 0, g, 1, eng.default_params(gapped=0, strand=1, hspthresh=1150, entropy=0))
+    st = eng.stats()
+    assert st['hsps'] > 50_000
+    exp = O.ungapped_hsps(seqs[0].tobytes(), seqs[1].tobytes(), 0, O.default_params(hspthresh=1150, entropy=0))
+    assert exp.size == st['hsps']
+    exp = exp[(exp['flags'] & 1) == 1]
+    assert got.size == exp.size > 300
+    order = np.lexsort((exp['length'], exp['qstart'], exp['tstart'], -exp['score']))   # anchor order
+    e = exp[order]
+    assert np.array_equal(got['tstart'], e['tstart']) and np.array_equal(got['qstart'], e['qstart'])
+    assert np.array_equal(got['tend'] - got['tstart'], e['length']) and np.array_equal(got['score'], e['score'])
+    g.close()
