@@ -256,11 +256,13 @@ int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t
  * Tandem-repeat content of genome slices: the role of `trf F 2 7 7 80 10 50 50 -m -h -ngs` in
  * wrappers.py:120-262 trfFilter (flags run_map.py:145-178).  masked[k] = number of bases of
  * iv[k] = [start, end) on scaffold `chrom` of A that the tandem scorer (K8, DESIGN.md "Tandem
- * scorer v1") marks; the host keeps a hit if 100*masked/len < maxtandem (wrappers.py:237-240).
- * `masked` is a caller-owned array of n entries.  maxperiod <= 64.
+ * scorer v2") marks; the host keeps a hit if 100*masked/len < maxtandem (wrappers.py:237-240).
+ * match / mismatch / delta / minscore / maxperiod are TRF's weights and thresholds of the same
+ * names (delta = indel penalty; delta <= 0: gap-free comparison); TRF's detection statistics PM and
+ * PI have no counterpart.  `masked` is a caller-owned array of n entries.  maxperiod <= 64.
  */
 int mimeo_tandem_masked(const mimeo_genome *A, const mimeo_interval *iv, uint64_t n, int32_t match,
-                        int32_t mismatch, int32_t minscore, int32_t maxperiod, uint32_t *masked);
+                        int32_t mismatch, int32_t delta, int32_t minscore, int32_t maxperiod, uint32_t *masked);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,7 @@ def load():
     if hasattr(lib, 'mimeo_coverage_collapse'):
         lib.mimeo_coverage_collapse.argtypes = [vp, u64, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)]
     if hasattr(lib, 'mimeo_tandem_masked'):
-        lib.mimeo_tandem_masked.argtypes = [vp, vp, u64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+        lib.mimeo_tandem_masked.argtypes = [vp, vp, u64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     if lib.mimeo_abi_version() != ABI_VERSION:
         raise RuntimeError('libmimeo_hip.so ABI %d != expected %d' % (lib.mimeo_abi_version(), ABI_VERSION))
     _lib = lib

@@ -342,11 +342,11 @@ int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t
 }
 
 int mimeo_tandem_masked(const mimeo_genome *A, const mimeo_interval *iv, uint64_t n, int32_t match, int32_t mismatch,
-                        int32_t minscore, int32_t maxperiod, uint32_t *masked) {
+                        int32_t delta, int32_t minscore, int32_t maxperiod, uint32_t *masked) {
     int rc = need_init();
     if (rc) return rc;
     if (!A || (n && (!iv || !masked))) { set_error("null argument"); return MIMEO_ERR_ARG; }
-    return tandem_masked_device(A, iv, n, match, mismatch, minscore, maxperiod, masked);
+    return tandem_masked_device(A, iv, n, match, mismatch, delta, minscore, maxperiod, masked);
 }
 
 }  // extern "C"

@@ -234,7 +234,7 @@ int ungapped_units(const std::vector<UnitWork> &work, const mimeo_params *p, std
 int build_kept_indexes(mimeo_genome *g, const uint32_t *scaf, uint64_t n);  // pipeline.hip
 
 // K8: tandem scorer (k8_tandem.hip); host in, host out
-int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch,
+int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch, int delta,
                          int minscore, int maxperiod, uint32_t *h_masked);
 
 }  // namespace mimeo

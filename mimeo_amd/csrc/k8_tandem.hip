@@ -4,15 +4,19 @@
 // replaced by N and keeps the hit if it is below --maxtandem (wrappers.py:237-240).
 //
 // PARITY UNPINNED: TRF is an external heuristic program that is absent here; this is a
-// specification of our own (DESIGN.md "Tandem scorer v1"), restated on the CPU in
-// oracle/pipeline.py.  For every period p = 1..maxperiod the slice is compared with itself
-// shifted by p (+match for an identical ACGT pair, -mismatch otherwise; no indels).  Scanning
-// left to right with a running score that restarts when it drops to <= 0, a segment whose best
-// prefix reaches minscore marks [segment start, best end + p) as tandem.  The masked set is
-// the union over the periods.
+// specification of our own (DESIGN.md "Tandem scorer v2"), restated on the CPU in
+// oracle/pipeline.py.  Like TRF it scores a candidate period p by aligning the sequence with a copy of itself p
+// bases back, with TRF's three weights: +match, -mismatch, -delta per inserted or deleted base.  For every period
+// p = 1 .. maxperiod the slice is aligned locally (scores restart at 0) with itself on the diagonals p - b .. p + b
+// (b = 0 for p = 1, 1 for p < 5, else 2: a copy may drift by that many bases through indels):
+//   H[j][d] = max(0, H[j-1][d] + s(S[j], S[j-d]), H[j-1][d-1] - delta, H[j][d+1] - delta)
+// (ties: diagonal move, then the insertion, then the deletion); a path that reaches a new best >= minscore marks
+// everything from the first base of its earlier copy to the base it has reached.  The masked set is the union over
+// the periods.  delta <= 0 switches the indel moves off (b = 0): the gap-free scorer of round 1.  TRF's detection
+// statistics (PM, PI) have no counterpart: every period is simply tried.
 //
-// One wavefront per slice, lane = period: each lane streams the slice 32 bases at a time with
-// bit-parallel self-comparison masks; qualified segments are OR-ed into a per-slice bitmask.
+// One wavefront per slice, lane = period: each lane streams the slice 32 bases at a time with bit-parallel
+// self-comparison masks per diagonal; qualified stretches are OR-ed into a per-slice bitmask.
 #include "device_util.h"
 
 namespace mimeo {
@@ -27,9 +31,12 @@ __device__ __forceinline__ void mark_range(uint32_t *__restrict__ bits, uint32_t
     }
 }
 
+constexpr int TBAND = 5;   // diagonals per period at most (b = 2)
+struct TCell { int32_t h; uint32_t start, best, mend; };   // score; first base of the earlier copy; best on the path; masked up to
+
 __global__ __launch_bounds__(256) void k8_tandem_mask(const StrandView *__restrict__ views,
                                                       const mimeo_interval *__restrict__ iv, uint64_t n,
-                                                      const uint64_t *__restrict__ word_off, int match, int mismatch,
+                                                      const uint64_t *__restrict__ word_off, int match, int mismatch, int delta,
                                                       int minscore, int maxperiod, uint32_t *__restrict__ bits) {
     const uint64_t wid = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     if (wid >= n) return;
@@ -40,26 +47,56 @@ __global__ __launch_bounds__(256) void k8_tandem_mask(const StrandView *__restri
     const uint32_t end = min(v.end, S.len);
     if (v.start >= end) return;
     const uint32_t L = end - v.start;
-    if (L <= p) return;
+    const uint32_t b = delta > 0 ? (p == 1 ? 0u : (p < 5 ? 1u : 2u)) : 0u, nd = 2 * b + 1, d0 = p - b;   // diagonals d0 .. d0 + nd - 1
+    if (L <= d0) return;
     uint32_t *mybits = bits + word_off[wid];
-    const uint32_t ncmp = L - p;  // comparable positions i in [0, L-p)
-    int32_t run = 0, best = 0;
-    uint32_t seg = 0, bestend = 0;
-    for (uint32_t i0 = 0; i0 < ncmp; i0 += 32) {
-        const Win32 a = win32(S, (int32_t)(v.start + i0)), b = win32(S, (int32_t)(v.start + i0 + p));
-        uint32_t eq = ~((a.lo ^ b.lo) | (a.hi ^ b.hi)) & ~(a.nm | b.nm);
-        const uint32_t cnt = min(32u, ncmp - i0);
-        for (uint32_t k = 0; k < cnt; k++) {
-            run += ((eq >> k) & 1u) ? match : -mismatch;
-            if (run <= 0) {
-                if (best >= minscore) mark_range(mybits, seg, min(L, bestend + p));
-                run = 0; best = 0; seg = i0 + k + 1;
-            } else if (run > best) {
-                best = run; bestend = i0 + k + 1;
+    TCell cur[TBAND], prev[TBAND];
+#pragma unroll
+    for (int k = 0; k < TBAND; k++) prev[k] = TCell{0, 0, 0, 0};
+    for (uint32_t j0 = (d0 / 32u) * 32u; j0 < L; j0 += 32) {
+        const Win32 a = win32(S, (int32_t)(v.start + j0));
+        uint32_t eq[TBAND];
+#pragma unroll
+        for (int k = 0; k < TBAND; k++) {
+            eq[k] = 0;
+            if ((uint32_t)k < nd) {
+                const Win32 c = win32(S, (int32_t)(v.start + j0) - (int32_t)(d0 + k));
+                eq[k] = ~((a.lo ^ c.lo) | (a.hi ^ c.hi)) & ~(a.nm | c.nm);
             }
         }
+        const uint32_t cnt = min(32u, L - j0);
+        for (uint32_t t = 0; t < cnt; t++) {
+            const uint32_t j = j0 + t;
+#pragma unroll
+            for (int k = TBAND - 1; k >= 0; k--) {
+                if ((uint32_t)k >= nd) continue;
+                const uint32_t d = d0 + (uint32_t)k;
+                TCell c{0, 0, 0, 0};
+                if (j >= d) {
+                    // diagonal move (a fresh path starts at the earlier copy's base j - d)
+                    const TCell &pd = prev[k];
+                    const int32_t sc = ((eq[k] >> t) & 1u) ? match : -mismatch;
+                    c.h = pd.h + sc;
+                    c.start = pd.h > 0 ? pd.start : j - d;
+                    c.best = pd.h > 0 ? pd.best : 0;
+                    c.mend = pd.h > 0 ? pd.mend : 0;
+                    if (k > 0 && prev[k - 1].h - delta > c.h) { c = prev[k - 1]; c.h -= delta; }          // insertion: (j-1, d-1)
+                    if ((uint32_t)k + 1 < nd && cur[k + 1].h - delta > c.h) { c = cur[k + 1]; c.h -= delta; }  // deletion: (j, d+1)
+                    if (c.h <= 0) c = TCell{0, 0, 0, 0};
+                    else if ((uint32_t)c.h > c.best) {
+                        c.best = (uint32_t)c.h;
+                        if (c.h >= minscore) {
+                            mark_range(mybits, max(c.mend, c.start), j + 1);
+                            c.mend = j + 1;
+                        }
+                    }
+                }
+                cur[k] = c;
+            }
+#pragma unroll
+            for (int k = 0; k < TBAND; k++) prev[k] = cur[k];
+        }
     }
-    if (best >= minscore) mark_range(mybits, seg, min(L, bestend + p));
 }
 
 __global__ void k8_tandem_count(const mimeo_interval *__restrict__ iv, uint64_t n, const uint64_t *__restrict__ word_off,
@@ -73,7 +110,7 @@ __global__ void k8_tandem_count(const mimeo_interval *__restrict__ iv, uint64_t 
     if (lane == 0) masked[wid] = c;
 }
 
-int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch,
+int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint64_t n, int match, int mismatch, int delta,
                          int minscore, int maxperiod, uint32_t *h_masked) {
     if (!n) return 0;
     if (maxperiod < 1 || maxperiod > 64) { set_error("tandem scorer: maxperiod must be in 1..64"); return MIMEO_ERR_LIMIT; }
@@ -99,7 +136,7 @@ int tandem_masked_device(const mimeo_genome *A, const mimeo_interval *h_iv, uint
     HIP_TRY(hipMemsetAsync(dm.p, 0, n * 4, st));
     const uint32_t nb = (uint32_t)((n * 64 + 255) / 256);
     hipLaunchKernelGGL(k8_tandem_mask, dim3(nb), dim3(256), 0, st, (const StrandView *)dv.p, (const mimeo_interval *)di.p, n,
-                       (const uint64_t *)dof.p, match, mismatch, minscore, maxperiod, (uint32_t *)db.p);
+                       (const uint64_t *)dof.p, match, mismatch, delta, minscore, maxperiod, (uint32_t *)db.p);
     hipLaunchKernelGGL(k8_tandem_count, dim3(nb), dim3(256), 0, st, (const mimeo_interval *)di.p, n,
                        (const uint64_t *)dof.p, (const uint32_t *)db.p, (uint32_t *)dm.p);
     HIP_TRY(hipMemcpyAsync(h_masked, dm.p, n * 4, hipMemcpyDeviceToHost, st));

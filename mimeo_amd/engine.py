@@ -157,7 +157,7 @@ def coverage_collapse(intervals, chrom_len, min_cov, min_len):
     return _ffi.take(ptr, n, _ffi.INTERVAL)
 
 
-def tandem_masked(A, intervals, match=2, mismatch=7, minscore=50, maxperiod=50):
+def tandem_masked(A, intervals, match=2, mismatch=7, minscore=50, maxperiod=50, delta=7):
     """Bases of each (scaffold id, start, end) slice of genome A marked by the tandem scorer (K8)."""
     iv = np.asarray(intervals)
     if iv.dtype != _ffi.INTERVAL:
@@ -167,6 +167,6 @@ def tandem_masked(A, intervals, match=2, mismatch=7, minscore=50, maxperiod=50):
     iv = np.ascontiguousarray(iv)
     out = np.zeros(iv.size, dtype=np.uint32)
     if iv.size:
-        _ffi.check(_ffi.load().mimeo_tandem_masked(A._h, iv.ctypes.data, iv.size, int(match), int(mismatch),
+        _ffi.check(_ffi.load().mimeo_tandem_masked(A._h, iv.ctypes.data, iv.size, int(match), int(mismatch), int(delta),
                                                    int(minscore), int(maxperiod), out.ctypes.data))
     return out

@@ -1,6 +1,6 @@
 """`mimeo filter` — drop library sequences that are mostly tandem repeats (reference:
 src/mimeo/run_filter.py:127-210 + wrappers.py:265-377 trfFasta).  The on-GPU tandem scorer (K8,
-DESIGN.md "Tandem scorer v1") stands in for `trf ... -m -h -ngs`: a record stays when
+DESIGN.md "Tandem scorer v2") stands in for `trf ... -m -h -ngs`: a record stays when
 (masked + N) / len * 100 < maxtandem, the test trfFasta applies to TRF's masked output
 (wrappers.py:369-371).  PARITY UNPINNED against TRF itself (absent here)."""
 import argparse
@@ -24,8 +24,8 @@ def mainArgs(argv=None):
     parser.add_argument('--TRFpath', type=str, default='trf', help='Accepted for compatibility; TRF is not used.')
     parser.add_argument('--tmatch', type=int, default=2, help='Tandem scorer matching weight')
     parser.add_argument('--tmismatch', type=int, default=7, help='Tandem scorer mismatching penalty')
-    parser.add_argument('--tdelta', type=int, default=7, help='Accepted for compatibility (gap-free scorer).')
-    parser.add_argument('--tPM', type=int, default=80, help='Accepted for compatibility.')
+    parser.add_argument('--tdelta', type=int, default=7, help='Tandem scorer indel penalty (0: gap-free comparison)')
+    parser.add_argument('--tPM', type=int, default=80, help='Accepted for compatibility (no detection statistics: every period is tried).')
     parser.add_argument('--tPI', type=int, default=10, help='Accepted for compatibility.')
     parser.add_argument('--tminscore', type=int, default=50, help='Minimum tandem score to mask')
     parser.add_argument('--tmaxperiod', type=int, default=50, help='Maximum period size to score (<= 64).')
@@ -36,13 +36,13 @@ def mainArgs(argv=None):
     return parser.parse_args(argv)
 
 
-def filter_fasta(infile, outfile, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, verbose=False):
+def filter_fasta(infile, outfile, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, verbose=False, tdelta=7):
     """wrappers.py:265-377 trfFasta; returns the ids kept (in file order)."""
     G = engine.Genome.from_fasta(infile)
     headers = []
     names, seqs = formats.read_fasta(infile, headers)  # the text is needed again to write the survivors
     iv = np.array([(i, 0, ln) for i, ln in enumerate(G.lengths)], dtype=np.uint32).reshape(-1, 3)
-    masked = engine.tandem_masked(G, iv, tmatch, tmismatch, tminscore, tmaxperiod)
+    masked = engine.tandem_masked(G, iv, tmatch, tmismatch, tminscore, tmaxperiod, tdelta)
     G.close()
     keep = []
     for n, s, m in zip(names, seqs, masked.tolist()):
@@ -81,7 +81,7 @@ def main(argv=None):
         logging.error('Input fasta not found at path: %s' % infile)
         raise SystemExit(1)
     keep = filter_fasta(infile, os.path.join(outdir, outname), args.tmatch, args.tmismatch, args.tminscore, args.tmaxperiod,
-                        args.maxtandem, args.verbose)
+                        args.maxtandem, args.verbose, args.tdelta)
     logging.info('Kept %d sequences.' % len(keep))
     logging.info('Finished!')
 

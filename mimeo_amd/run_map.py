@@ -13,9 +13,11 @@ def mainArgs(argv=None):
         description='Find all high-identity segments shared between genomes.', prog='mimeo-map')
     _cli.add_common(parser, 'mimeo-map', None, 'BHit', 'BHit', with_b=True)
     parser.add_argument('--TRFpath', type=str, default='trf', help='Accepted for compatibility; TRF is not used.')
-    for name, default in (('tmatch', 2), ('tmismatch', 7), ('tdelta', 7), ('tPM', 80), ('tPI', 10), ('tminscore', 50),
-                          ('tmaxperiod', 50)):
-        parser.add_argument('--' + name, type=int, default=default, help='TRF parameter (tandem filter).')
+    for name, default, what in (('tmatch', 2, 'matching weight'), ('tmismatch', 7, 'mismatching penalty'), ('tdelta', 7, 'indel penalty'),
+                                ('tPM', 80, 'match probability: accepted for compatibility, the on-GPU scorer tries every period (no detection statistics)'),
+                                ('tPI', 10, 'indel probability: accepted for compatibility (as --tPM)'),
+                                ('tminscore', 50, 'minimum alignment score of a tandem repeat'), ('tmaxperiod', 50, 'maximum period size (<= 64)')):
+        parser.add_argument('--' + name, type=int, default=default, help='Tandem scorer (TRF parameter of the same name): %s.' % what)
     parser.add_argument('--maxtandem', type=float, default=None,
                         help='Max percentage of an A-genome alignment which may be masked by TRF.')
     parser.add_argument('--writeTRF', action='store_true', default=False, help='Write TRF-filtered alignment file.')
@@ -46,7 +48,7 @@ def main(argv=None):
         if args.maxtandem:  # run_map.py:293-314: tandem filter, optional .trf table
             logging.info('Filtering alignments by tandem repeat content...')
             rows = workflow.trf_filter(rows, A, prefix=args.prefix, tmatch=args.tmatch, tmismatch=args.tmismatch,
-                                       tminscore=args.tminscore, tmaxperiod=args.tmaxperiod, maxtandem=args.maxtandem)
+                                       tminscore=args.tminscore, tmaxperiod=args.tmaxperiod, maxtandem=args.maxtandem, tdelta=args.tdelta)
             if args.writeTRF:
                 logging.info('Writing TRF-filtered alignments to file: %s' % (outtab + '.trf'))
                 formats.write_trf_tab(rows, outtab)

@@ -117,15 +117,15 @@ def map_hits(A, B, pairs, outtab, minIdt=95, minLen=100, hspthresh=3000, reuseTa
             write_tab(outtab, pairs, blocks)
 
 
-def trf_filter(rows, A, prefix=None, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40):
+def trf_filter(rows, A, prefix=None, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, tdelta=7):
     """wrappers.py:120-262 trfFilter with the on-GPU tandem scorer (K8) in the place of TRF: the
     slice is seq[int(tStart):int(tEnd)] exactly as the reference cuts it (origin-one start used as
     a 0-based index, wrappers.py:190), a hit stays if masked/len*100 < maxtandem (:237-240), then
-    the survivors are re-sorted and renumbered (:243-259).  tdelta / tPM / tPI have no counterpart
-    in the gap-free scorer."""
+    the survivors are re-sorted and renumbered (:243-259).  tmatch / tmismatch / tdelta / tminscore /
+    tmaxperiod are TRF's weights and thresholds; its detection statistics tPM / tPI have no counterpart."""
     cid = {n: i for i, n in enumerate(A.names)}
     iv = np.array([(cid[r[0]], int(r[2]), int(r[3])) for r in rows], dtype=np.uint32).reshape(-1, 3)
-    masked = engine.tandem_masked(A, iv, tmatch, tmismatch, tminscore, tmaxperiod)
+    masked = engine.tandem_masked(A, iv, tmatch, tmismatch, tminscore, tmaxperiod, tdelta)
     keep = []
     for r, m, (c, s, e) in zip(rows, masked.tolist(), iv.tolist()):
         ln = min(e, A.lengths[c]) - s

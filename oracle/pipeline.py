@@ -137,37 +137,56 @@ def gff_map_lines(rows, chromlens, ftype='BHit'):
     return lines
 
 
-def tandem_masked(seq, start, end, match=2, mismatch=7, minscore=50, maxperiod=50):
-    """CPU restatement of the tandem scorer v1 that stands in for
+def tandem_masked(seq, start, end, match=2, mismatch=7, minscore=50, maxperiod=50, delta=7):
+    """CPU restatement of the tandem scorer v2 that stands in for
     `trf F 2 7 7 80 10 50 50 -m -h -ngs` in wrappers.py:120-262.  PARITY UNPINNED: TRF itself is
-    absent; this restates OUR specification, not TRF's heuristics.  seq: bytes; returns the number
-    of masked bases of seq[start:end]."""
+    absent; this restates OUR specification, not TRF's heuristics.  For every period p the slice is
+    aligned locally with itself on the diagonals p-b .. p+b (b = 0 for p = 1, 1 for p < 5, else 2;
+    delta <= 0: b = 0, the gap-free scorer of round 1):
+      H[j][d] = max(0, H[j-1][d] + s(S[j], S[j-d]), H[j-1][d-1] - delta, H[j][d+1] - delta)
+    (ties: diagonal, insertion, deletion); a path that reaches a new best >= minscore masks everything
+    from the first base of its earlier copy to the base it has reached.  seq: bytes; returns the
+    number of masked bases of seq[start:end]."""
     s = seq[start:end].upper()
     L = len(s)
     masked = bytearray(L)
     ok = [c in b'ACGT' for c in s]
     for p in range(1, maxperiod + 1):
-        if L <= p:
-            break
-        run = best = 0
-        seg = bestend = 0
-        for i in range(L - p):
-            run += match if (ok[i] and ok[i + p] and s[i] == s[i + p]) else -mismatch
-            if run <= 0:
-                if best >= minscore:
-                    for k in range(seg, min(L, bestend + p)):
-                        masked[k] = 1
-                run = best = 0
-                seg = i + 1
-            elif run > best:
-                best, bestend = run, i + 1
-        if best >= minscore:
-            for k in range(seg, min(L, bestend + p)):
-                masked[k] = 1
+        b = (0 if p == 1 else (1 if p < 5 else 2)) if delta > 0 else 0
+        nd, d0 = 2 * b + 1, p - b
+        if L <= d0:
+            continue
+        prev = [(0, 0, 0, 0)] * nd          # (h, start, best, mend)
+        for j in range((d0 // 32) * 32, L):
+            cur = [(0, 0, 0, 0)] * nd
+            for k in range(nd - 1, -1, -1):
+                d = d0 + k
+                c = (0, 0, 0, 0)
+                if j >= d:
+                    ph, pst, pbest, pmend = prev[k]
+                    sc = match if (ok[j] and ok[j - d] and s[j] == s[j - d]) else -mismatch
+                    c = (ph + sc, pst, pbest, pmend) if ph > 0 else (sc, j - d, 0, 0)
+                    if k > 0 and prev[k - 1][0] - delta > c[0]:
+                        q = prev[k - 1]
+                        c = (q[0] - delta, q[1], q[2], q[3])
+                    if k + 1 < nd and cur[k + 1][0] - delta > c[0]:
+                        q = cur[k + 1]
+                        c = (q[0] - delta, q[1], q[2], q[3])
+                    if c[0] <= 0:
+                        c = (0, 0, 0, 0)
+                    elif c[0] > c[2]:
+                        h, st, _, mend = c
+                        if h >= minscore:
+                            for x in range(max(mend, st), j + 1):
+                                masked[x] = 1
+                            mend = j + 1
+                        c = (h, st, h, mend)
+                cur[k] = c
+            prev = cur
     return sum(masked)
 
 
-def trf_filter(rows, seq_of, prefix=None, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, masked_fn=None):
+def trf_filter(rows, seq_of, prefix=None, tmatch=2, tmismatch=7, tminscore=50, tmaxperiod=50, maxtandem=40, masked_fn=None, tdelta=7):
     """wrappers.py:120-262 trfFilter with `tandem_masked` in TRF's place: slice seq[int(tStart):int(tEnd)]
     of the origin-one start (wrappers.py:190), keep while masked / len * 100 < maxtandem (:237-240), then the
     string sort and renumbering of :243-259.  rows: import_align rows; seq_of: name -> bytes."""
@@ -175,7 +194,7 @@ def trf_filter(rows, seq_of, prefix=None, tmatch=2, tmismatch=7, tminscore=50, t
     keep = []
     for r in rows:
         s, e = int(r[2]), min(int(r[3]), len(seq_of[r[0]]))
-        if e - s > 0 and fn(seq_of[r[0]], s, e, tmatch, tmismatch, tminscore, tmaxperiod) / (e - s) * 100 < float(maxtandem):
+        if e - s > 0 and fn(seq_of[r[0]], s, e, tmatch, tmismatch, tminscore, tmaxperiod, tdelta) / (e - s) * 100 < float(maxtandem):
             keep.append(r[:10])
     keep.sort(key=lambda f: (f[0], f[2], f[3], f[1]))
     width = len(str(len(keep)))

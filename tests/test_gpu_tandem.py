@@ -52,10 +52,48 @@ def test_tandem_masked_equals_cpu_restatement(eng):
             a = int(rng.integers(0, len(seqs[c]) - 2500))
             iv.append((c, a, a + int(rng.integers(1, 2400))))
     iv += [(0, 10, 10), (0, 5, 6), (1, 29990, 40000), (0, 495, 530)]
-    for params in ((2, 7, 50, 50), (2, 5, 30, 12), (3, 7, 80, 64)):
+    # (match, mismatch, minscore, maxperiod, delta): TRF's defaults, variations, and delta 0 = the gap-free scorer
+    for params in ((2, 7, 50, 50, 7), (2, 5, 30, 12, 3), (3, 7, 80, 64, 9), (2, 7, 50, 50, 0)):
         got = eng.tandem_masked(g, np.array(iv, dtype=np.uint32), *params)
         exp = [P.tandem_masked(seqs[c].tobytes(), s, min(e, len(seqs[c])), *params) for c, s, e in iv]
         assert got.tolist() == exp, params
+    g.close()
+
+
+def test_ssrs_with_indels_are_masked(eng):
+    """What v2 is for: microsatellites carry indels (TRF's default model expects 10 %).  Arrays of period 2-6 and
+    10 with 2 % single-base insertions / deletions plus 2 % substitutions must still be masked almost entirely with the
+    indel moves on (tdelta 7), never less than by the gap-free comparison (tdelta 0: an indel costs it a period's worth
+    of mismatches, which splits long periods into segments); random sequence stays unmasked either way."""
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b'ACGT', np.uint8)
+    seq = acgt[rng.integers(0, 4, 40_000)].copy()
+    spans = []
+    pos = 1000
+    for unit in (b'AC', b'AAG', b'ACGT', b'AAAAG', b'ACACGT', b'ACGTTGCAAC'):
+        ln = 600
+        rep = bytearray((unit * (ln // len(unit) + 2))[:ln])
+        out = bytearray()
+        for c in rep:
+            r = rng.random()
+            if r < 0.01:
+                continue                                  # deletion
+            if r < 0.02:
+                out.append(int(acgt[rng.integers(0, 4)]))  # insertion in front
+            if rng.random() < 0.02:
+                c = int(acgt[rng.integers(0, 4)])
+            out.append(c)
+        seq[pos:pos + len(out)] = np.frombuffer(bytes(out), np.uint8)
+        spans.append((pos, pos + len(out)))
+        pos += 3000
+    g = eng.Genome(['s'], [seq])
+    iv = np.array([(0, a, b) for a, b in spans], dtype=np.uint32)
+    with_indels = eng.tandem_masked(g, iv, 2, 7, 50, 50, 7) / np.array([b - a for a, b in spans])
+    gap_free = eng.tandem_masked(g, iv, 2, 7, 50, 50, 0) / np.array([b - a for a, b in spans])
+    assert (with_indels > 0.85).all(), with_indels
+    assert (with_indels >= gap_free - 1e-9).all(), (with_indels, gap_free)
+    rnd = np.array([(0, a, a + 1000) for a in range(20_000, 38_000, 1000)], dtype=np.uint32)
+    assert (eng.tandem_masked(g, rnd, 2, 7, 50, 50, 7) / 1000.0 < 0.08).all()
     g.close()
 
 
