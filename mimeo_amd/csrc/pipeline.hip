@@ -5,14 +5,15 @@
 // built once and kept for the whole call (lastz rebuilds its table in every one of the S^2 invocations).  The
 // (target, query, strand) units are worked off in BATCHES — a target row of a C4 job: 200 units — and a batch
 // is one straight stream of device work with four host round trips in all:
-//   heavy phase   one fused seed-scan / pre-filter / exact-walk kernel per unit (K34), back to back, nothing
-//                 read back, appending to batch-wide queues tagged with the unit
+//   heavy phase   per unit: the fused seed-scan / pre-filter kernel (K34), the sharp filter + exact walk of the hits it
+//                 passes on (k4_extend_hits on the unit's walk queue), a queue reset — back to back, nothing read
+//                 back, appending to batch-wide queues tagged with the unit
 //   tails         walks beyond the frame, one radix sort of the followers of ALL units, segment resolution,
 //                 entropy (K4; two round trips: follower count, HSP count)
 //   K5 / K6       chain and gapped extension of all units of the batch (one workgroup per unit in K5,
 //                 wavefronts per half extension in K6; round trips per DP round)
 // Round 1 issued the tails per unit (~10 launches, 19 merge-sort passes and two host round trips each, three
-// host threads to hide them); a C4 row now costs ~230 launches instead of ~6000.
+// host threads to hide them); a C4 row now costs ~830 launches instead of ~6000.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
