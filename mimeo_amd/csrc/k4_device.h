@@ -16,6 +16,10 @@ constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per 
 // kernels look the two strands up in the unit table.
 struct ExtCounters {
     unsigned long long ncand, nfollow, nlong, nhsp, nmed, nbig, nwalked;  // nwalked: hits the pre-filter let through
+    // The two busy queues — followers and hits whose walk outlives the frame — are filled in eight shards (workgroup
+    // number mod 8, i.e. per XCD: region r = [r * cap, ...)): a same-address atomic serialises at ~13 ns and a C4 unit
+    // makes ~10^4 flushes.  nfollow / nmed hold the totals once k4_compact has gathered the follower shards.
+    unsigned long long nfollow8[8], nmed8[8];
     unsigned long long nwalk[8];   // entries of the walk queue of the current unit (K34 -> k4_extend_hits on the queue), in eight
                                    // shards (workgroup number mod 8, i.e. per XCD): 50 000 flushes per unit on ONE counter
                                    // would serialise at ~13 ns each
@@ -49,9 +53,10 @@ struct ExtQueues {
     unsigned long long *bigacc;     // ... matched A / C / G / T columns, raw score
     unsigned long long *unit_hits;  // seed hits per unit (statistics)
     unsigned long long *tile_hits;  // ... per unit and tile (K34 writes them, k34_sum_hits folds them into unit_hits)
-    uint64_t cand_cap, follow_cap, med_cap, long_cap, walk_cap;   // walk_cap: per shard (shard r = walkq[r * walk_cap ...])
+    uint64_t cand_cap, follow_cap, med_cap, long_cap, walk_cap;   // follow_cap, med_cap, walk_cap: per shard (shard r = base[r * cap ...])
     uint32_t ebits, dbits;
 };
+__device__ __forceinline__ uint32_t queue_shard() { return blockIdx.x & 7u; }
 // a slot of an append-only queue for every lane that calls this together: one atomic per wavefront (same-address
 // atomics serialise at ~13 ns each)
 __device__ __forceinline__ unsigned long long wave_slot(unsigned long long *counter) {
@@ -527,10 +532,10 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
         if (f.n_med + add > (uint32_t)CAP || (final && !m)) {
             __builtin_amdgcn_wave_barrier();  // LDS accesses of one wavefront execute in order
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&q.ctr->nmed, (unsigned long long)f.n_med);
+            if (lane == 0) b = atomicAdd(&q.ctr->nmed8[queue_shard()], (unsigned long long)f.n_med);
             b = __shfl(b, 0);
             for (uint32_t i = lane; i < f.n_med; i += 64)
-                if (b + i < q.med_cap) { q.medq[b + i] = s_med[i]; q.medu[b + i] = unit; }
+                if (b + i < q.med_cap) { const size_t at = (size_t)queue_shard() * q.med_cap + b + i; q.medq[at] = s_med[i]; q.medu[at] = unit; }
             f.n_med = 0;
             __builtin_amdgcn_wave_barrier();
         }
@@ -539,10 +544,10 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
         if (final && f.n_med) {
             __builtin_amdgcn_wave_barrier();
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&q.ctr->nmed, (unsigned long long)f.n_med);
+            if (lane == 0) b = atomicAdd(&q.ctr->nmed8[queue_shard()], (unsigned long long)f.n_med);
             b = __shfl(b, 0);
             for (uint32_t i = lane; i < f.n_med; i += 64)
-                if (b + i < q.med_cap) { q.medq[b + i] = s_med[i]; q.medu[b + i] = unit; }
+                if (b + i < q.med_cap) { const size_t at = (size_t)queue_shard() * q.med_cap + b + i; q.medq[at] = s_med[i]; q.medu[at] = unit; }
             f.n_med = 0;
         }
     }
@@ -552,10 +557,10 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
         if (f.n_fol + add > (uint32_t)CAP || (final && !m)) {
             __builtin_amdgcn_wave_barrier();
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&q.ctr->nfollow, (unsigned long long)f.n_fol);
+            if (lane == 0) b = atomicAdd(&q.ctr->nfollow8[queue_shard()], (unsigned long long)f.n_fol);
             b = __shfl(b, 0);
             for (uint32_t i = lane; i < f.n_fol; i += 64)
-                if (b + i < q.follow_cap) { q.fkey[b + i] = batch_key(q, unit, s_fk[i]); q.fprev[b + i] = s_fp[i]; }
+                if (b + i < q.follow_cap) { const size_t at = (size_t)queue_shard() * q.follow_cap + b + i; q.fkey[at] = batch_key(q, unit, s_fk[i]); q.fprev[at] = s_fp[i]; }
             f.n_fol = 0;
             __builtin_amdgcn_wave_barrier();
         }
@@ -564,10 +569,10 @@ __device__ __forceinline__ void stage_records(const ExtQueues &q, uint32_t unit,
         if (final && f.n_fol) {
             __builtin_amdgcn_wave_barrier();
             unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&q.ctr->nfollow, (unsigned long long)f.n_fol);
+            if (lane == 0) b = atomicAdd(&q.ctr->nfollow8[queue_shard()], (unsigned long long)f.n_fol);
             b = __shfl(b, 0);
             for (uint32_t i = lane; i < f.n_fol; i += 64)
-                if (b + i < q.follow_cap) { q.fkey[b + i] = batch_key(q, unit, s_fk[i]); q.fprev[b + i] = s_fp[i]; }
+                if (b + i < q.follow_cap) { const size_t at = (size_t)queue_shard() * q.follow_cap + b + i; q.fkey[at] = batch_key(q, unit, s_fk[i]); q.fprev[at] = s_fp[i]; }
             f.n_fol = 0;
         }
     }
@@ -793,8 +798,9 @@ __device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2
                           : wave_walk_fast(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop);
     if (L.found) {
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long i = atomicAdd(&q.ctr->nfollow, 1ull);
+            unsigned long long i = atomicAdd(&q.ctr->nfollow8[queue_shard()], 1ull);
             if (i < q.follow_cap) {
+                i += (unsigned long long)queue_shard() * q.follow_cap;
                 q.fkey[i] = follow_key(q, unit, d, Q.len, (uint32_t)et);
                 q.fprev[i] = L.prev_end;
             }

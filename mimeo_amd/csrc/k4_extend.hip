@@ -39,11 +39,22 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
     __shared__ uint32_t tab[GROUP_TAB];
     for (int i = threadIdx.x; i < GROUP_TAB; i += EXT_THREADS) tab[i] = group_tab[i];
     __syncthreads();
-    const uint64_t nhits = min((uint64_t)q.ctr->nmed, q.med_cap);  // count produced by the heavy kernels
+    // the hits come in eight shards (counts produced by the heavy kernels): sh_end[r] = hits in shards 0 .. r
+    uint64_t sh_end[8];
+    {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { acc += min((uint64_t)q.ctr->nmed8[r], q.med_cap); sh_end[r] = acc; }
+    }
+    const uint64_t nhits = sh_end[7];
     for (uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x; gid < nhits;
          gid += (uint64_t)gridDim.x * EXT_THREADS) {
-        const uint2 h = q.medq[gid];
-        const uint32_t unit = q.medu[gid];
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) r += gid >= sh_end[k] ? 1u : 0u;
+        const uint64_t at = (uint64_t)r * q.med_cap + (gid - (r ? sh_end[r - 1] : 0));
+        const uint2 h = q.medq[at];
+        const uint32_t unit = q.medu[at];
         const StrandView T = units[unit].T, Q = units[unit].Q;
         const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
         const int32_t d = (int32_t)h.x - (int32_t)h.y;
@@ -77,8 +88,9 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
                         __brev(H), maxl, xdrop);
         }
         if (!is_long && L.found) {
-            const unsigned long long i = wave_slot(&q.ctr->nfollow);   // one atomic for the lanes that are here together
+            unsigned long long i = wave_slot(&q.ctr->nfollow8[queue_shard()]);   // one atomic for the lanes that are here together
             if (i < q.follow_cap) {
+                i += (unsigned long long)queue_shard() * q.follow_cap;
                 q.fkey[i] = follow_key(q, unit, d, Q.len, (uint32_t)et);
                 q.fprev[i] = (uint32_t)et - L.found_step;  // position of the base just summed = that seed's end
             }
@@ -220,6 +232,23 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_long(const UnitDesc *__
     for (uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; wid < nlong; wid += nwaves) {
         const uint32_t unit = q.longu[wid];
         wave_extend_emit(units[unit].T, units[unit].Q, q.longq[wid], xdrop, hspthresh, transitions, true, q, unit, nullptr);
+    }
+}
+
+// ---- the follower shards gathered into one array (input of the sort) ---------------------------------------------
+__global__ __launch_bounds__(256) void k4_compact_followers(ExtQueues q, uint64_t *__restrict__ key, uint32_t *__restrict__ prev) {
+    uint64_t sh_end[8];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { acc += min((uint64_t)q.ctr->nfollow8[r], q.follow_cap); sh_end[r] = acc; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.ctr->nfollow = acc;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x; gid < acc; gid += (uint64_t)gridDim.x * 256) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) r += gid >= sh_end[k] ? 1u : 0u;
+        const uint64_t at = (uint64_t)r * q.follow_cap + (gid - (r ? sh_end[r - 1] : 0));
+        key[gid] = q.fkey[at];
+        prev[gid] = q.fprev[at];
     }
 }
 
@@ -636,17 +665,19 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     const double shrink = getenv("MIMEO_QUEUE_SHRINK") ? atof(getenv("MIMEO_QUEUE_SHRINK")) : 1.0;  // tests: force the rerun
     // `boost`: the largest excess over these shares that an earlier batch showed (a repeat-rich genome overflows the
     // first batch once, not every batch)
-    uint64_t cap_f = (uint64_t)(expect_hits * 0.02 * boost / shrink) + (uint64_t)(4194304 / shrink) + 64;
-    uint64_t cap_m = (uint64_t)(expect_hits * 0.03 * boost / shrink) + (uint64_t)(4194304 / shrink) + 64;
+    // (followers and generic-walk hits: capacity PER SHARD, eight shards, with half as much again for their imbalance)
+    uint64_t cap_f = (uint64_t)(expect_hits * 0.02 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    uint64_t cap_m = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     uint64_t cap_l = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     uint64_t cap_c = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
     uint64_t cap_w = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     ExtCounters c;
+    uint64_t nf_total = 0, nm_total = 0;
     float ms_heavy = 0, ms_tails = 0, ms_walk = 0, ms_k34 = 0;
     for (int attempt = 0;; attempt++) {
-        if ((rc = fkey.reserve(cap_f * 8)) || (rc = fprev.reserve(cap_f * 4)) || (rc = medq.reserve(cap_m * 8)) ||
-            (rc = medu.reserve(cap_m * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
+        if ((rc = fkey.reserve(cap_f * 8 * 8)) || (rc = fprev.reserve(cap_f * 8 * 4)) || (rc = medq.reserve(cap_m * 8 * 8)) ||
+            (rc = medu.reserve(cap_m * 8 * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
             (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp))) ||
             (rc = hsp_unit.reserve(cap_c * 4)) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8 * 8)))
             return rc;
@@ -723,29 +754,38 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         hipLaunchKernelGGL(k4_extend_long, dim3(256), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh, p->transitions);
         HIP_TRY(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // round trip 1: follower count (sizes the sort), overflow check
-        bool over = c.nfollow > cap_f || c.nmed > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > cap_w;
-        if (!over && c.nfollow) {
-            const uint64_t nf = c.nfollow;
+        uint64_t nf = 0, nm = 0, maxf = 0, maxm = 0;
+        for (int r = 0; r < 8; r++) {
+            nf += std::min<uint64_t>(c.nfollow8[r], cap_f);
+            nm += std::min<uint64_t>(c.nmed8[r], cap_m);
+            maxf = std::max<uint64_t>(maxf, c.nfollow8[r]);
+            maxm = std::max<uint64_t>(maxm, c.nmed8[r]);
+        }
+        nf_total = nf; nm_total = nm;
+        bool over = maxf > cap_f || maxm > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > cap_w;
+        if (!over && nf) {
             if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
                 (rc = segs.reserve(nf * 8)) || (rc = bigseg.reserve(nf * 8)))
                 return rc;
             size_t t1 = 0, t2 = 0;
-            HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)fkey.p, (uint64_t *)fkey2.p, (uint32_t *)fprev.p,
-                                              (uint32_t *)fprev2.p, (size_t)nf, 0, key_bits, st));
+            // the eight shards gathered into fkey2 / fprev2; the sort writes back into the (now free) shard area
+            hipLaunchKernelGGL(k4_compact_followers, dim3(1024), dim3(256), 0, st, q, (uint64_t *)fkey2.p, (uint32_t *)fprev2.p);
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
+                                              (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             rocprim::counting_iterator<uint64_t> iota(0);
             HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)flags.p, (uint64_t *)segs.p, (uint64_t *)nsel.p, (size_t)nf, st));
             if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc;
-            HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)fkey.p, (uint64_t *)fkey2.p, (uint32_t *)fprev.p,
-                                              (uint32_t *)fprev2.p, (size_t)nf, 0, key_bits, st));
-            hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st, (const uint64_t *)fkey2.p,
-                               (const uint32_t *)fprev2.p, nf, q, (uint8_t *)flags.p);
+            HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
+                                              (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
+            hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st, (const uint64_t *)fkey.p,
+                               (const uint32_t *)fprev.p, nf, q, (uint8_t *)flags.p);
             HIP_TRY(rocprim::select(tmp.p, t2, iota, (uint8_t *)flags.p, (uint64_t *)segs.p, (uint64_t *)nsel.p, (size_t)nf, st));
             // segments: at most nf of them; the kernels read the real number from nsel
             hipLaunchKernelGGL(k4_resolve_small, dim3((uint32_t)((nf + EXT_THREADS - 1) / EXT_THREADS)), dim3(EXT_THREADS), 0, st,
-                               d_units, q, (const uint64_t *)fkey2.p, (const uint32_t *)fprev2.p, nf, (const uint64_t *)segs.p,
+                               d_units, q, (const uint64_t *)fkey.p, (const uint32_t *)fprev.p, nf, (const uint64_t *)segs.p,
                                (const uint64_t *)nsel.p, p->xdrop, p->hspthresh, tab, (uint64_t *)bigseg.p);
-            hipLaunchKernelGGL(k4_resolve_segments, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, (const uint64_t *)fkey2.p,
-                               (const uint32_t *)fprev2.p, nf, (const uint64_t *)segs.p, (const uint64_t *)nsel.p,
+            hipLaunchKernelGGL(k4_resolve_segments, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, (const uint64_t *)fkey.p,
+                               (const uint32_t *)fprev.p, nf, (const uint64_t *)segs.p, (const uint64_t *)nsel.p,
                                (const uint64_t *)bigseg.p, p->xdrop, p->hspthresh, p->transitions);
         }
         if (!over) {
@@ -765,7 +805,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
                     c.dbg[0], c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7]);
         if (getenv("MIMEO_K4_STATS"))
             fprintf(stderr, "[k4] units %u walk queue %llu walked %llu generic %llu long %llu followers %llu candidates %llu hsps %llu%s\n", nunits,
-                    c.nwalk_total, c.nwalked, c.nmed, c.nlong, c.nfollow, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
+                    c.nwalk_total, c.nwalked, (unsigned long long)nm, c.nlong, (unsigned long long)nf, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
         if (!over) {
             float a = 0, b = 0, w = 0;
             HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
@@ -785,8 +825,8 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         }
         if (attempt >= 2) { set_error("extension queues overflowed twice in a row"); return MIMEO_ERR_LIMIT; }
         // room for what the counters saw, and half as much again: the repeated tails may add candidates of their own
-        cap_f = std::max<uint64_t>(cap_f, c.nfollow + c.nfollow / 2 + 1024);
-        cap_m = std::max<uint64_t>(cap_m, c.nmed + c.nmed / 2 + 1024);
+        cap_f = std::max<uint64_t>(cap_f, maxf + maxf / 2 + 1024);
+        cap_m = std::max<uint64_t>(cap_m, maxm + maxm / 2 + 1024);
         cap_l = std::max<uint64_t>(cap_l, c.nlong + c.nlong / 2 + 1024);
         cap_c = std::max<uint64_t>(cap_c, 2 * c.ncand + 65536);
         cap_w = std::max<uint64_t>(cap_w, c.nwalk_over + c.nwalk_over / 4 + 1024);
@@ -797,7 +837,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     *nhsp_out = c.nhsp;
     if (expect_hits > 1e6) {
         const double e = expect_hits;
-        const double r = std::max({(double)c.nfollow / (0.02 * e), (double)c.nmed / (0.03 * e), (double)c.nlong / (0.002 * e),
+        const double r = std::max({(double)nf_total / (0.02 * e), (double)nm_total / (0.03 * e), (double)c.nlong / (0.002 * e),
                                    (double)c.ncand / (0.002 * e), (double)c.nwalk_total / (0.12 * e)});
         boost = std::min(64.0, std::max(boost, 1.5 * r));
     }
@@ -815,7 +855,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         stats->walk_queue += c.nwalk_total;
         stats->ms_walk += ms_walk;
         stats->ms_k34 += v1 ? ms_heavy : ms_k34;
-        stats->followers += c.nfollow;
+        stats->followers += nf_total;
         stats->candidates += c.ncand;
         stats->ms_heavy += ms_heavy;
         stats->ms_tails += ms_tails;

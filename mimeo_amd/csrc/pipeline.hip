@@ -234,7 +234,10 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             }
             if (rc) break;
             uint64_t nh = 0;
+            static const bool timing = getenv("MIMEO_TIMING") != nullptr;   // development: host wall time of the phases of a batch
+            auto tb0 = std::chrono::steady_clock::now();
             if ((rc = g_ext.run(work, p, &nh, &est))) break;
+            auto tb1 = std::chrono::steady_clock::now();
             g_stats.pair_strands += work.size();
             g_stats.hsps += nh;
             for (size_t i = b0; i < b1; i++) g_stats.query_bases_scanned += QG->scaf[units[i].qid].len;
@@ -275,6 +278,12 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                     auto &dst = per_pair[units[b0 + gi].pair];
                     dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
                 }
+            }
+            if (timing) {
+                auto tb2 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[timing] batch of %zu units: extension stage %.2f ms (device heavy %.2f + tails %.2f), chain + gapped + read-back %.2f ms (device %.2f + %.2f)\n",
+                        work.size(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(), est.ms_heavy, est.ms_tails,
+                        std::chrono::duration<double, std::milli>(tb2 - tb1).count(), ms_chain, ms_gapped);
             }
             b0 = b1;
         }
