@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "device_util.h"
@@ -529,6 +530,261 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
     return best;
 }
 
+// ---- lean single-wavefront DP (k6_dp1): the production kernel -----------------------------------------------
+// Same recurrences, pruning and tie-breaks as wave_half_extend<16> (one wavefront, 16 columns per lane, 1024-column
+// window that slides by whole strips), written for VALU issue, which is what bounds K6 (profiles/r02_*: both
+// older kernels spend 1700+ issue slots per DP row):
+//   * counts packed (matches | mismatches << 16): one select instead of two;
+//   * no liveness guards: a dead cell is any value below NEGH, arithmetic on it stays below NEGH for the one row
+//     until pruning resets it to NEG, so max / compare need no special cases;
+//   * the substitution score of a cell is ONE v_perm_b32: the row's target base is wave-uniform, so the four
+//     possible scores (+128, as bytes) sit in a scalar register and the column's query base is a precomputed byte
+//     selector (selector 4 = the constant 28 = -100 + 128 of an N column; an N row is the table 0x1C1C1C1C);
+//   * the insertion state is carried in the frame of the current column (acc = max(acc, H) - E) instead of
+//     u_k = H_k + k E: no per-column constants; lanes are stitched with one max-scan of (aggregate + lane * 16 E);
+//   * per cell the row maximum is one v_max; which cell it was (smallest column on ties) is found with scalar
+//     reads only in rows that improve the best score; liveness is per strip (row maximum above NEGH), which is
+//     all the window slide and the overflow test ever needed;
+//   * columns beyond the end of the query only exist when the window touches it: rows of such windows run the
+//     EDGE variant (one extra mask test per cell), selected wave-uniformly.
+// ~28 VALU instructions per cell, ~520 per row.
+constexpr int L_WS = 16, L_WINDOW = 64 * L_WS;
+struct LeanState {
+    int32_t C[L_WS], D[L_WS];
+    uint32_t Cc[L_WS], Dc[L_WS], sel[L_WS];
+};
+
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// inclusive max-scan, ties to the lower lane; a lane without a source sees its own value (no identity moves)
+template <int CTRL, int RMASK>
+__device__ __forceinline__ PCell lean_scan_step(const PCell &v) {
+    PCell o;
+    o.s = __builtin_amdgcn_update_dpp(v.s, v.s, CTRL, RMASK, 0xf, false);
+    o.c = (uint32_t)__builtin_amdgcn_update_dpp((int)v.c, (int)v.c, CTRL, RMASK, 0xf, false);
+    return pcmax_left(o, v);
+}
+__device__ __forceinline__ PCell lean_incl_maxscan(PCell v) {
+    v = lean_scan_step<0x111, 0xf>(v);
+    v = lean_scan_step<0x112, 0xf>(v);
+    v = lean_scan_step<0x114, 0xf>(v);
+    v = lean_scan_step<0x118, 0xf>(v);
+    v = lean_scan_step<0x142, 0xa>(v);
+    v = lean_scan_step<0x143, 0xc>(v);
+    return v;
+}
+
+// byte selectors of a strip from its query bits: 0..3 = base code (lo | hi << 1), 4 = N; upper bytes select zero
+__device__ __forceinline__ void lean_selectors(LeanState &S, uint32_t qlo, uint32_t qhi, uint32_t qn) {
+#pragma unroll
+    for (int s = 0; s < L_WS; s++) {
+        const uint32_t idx = ((qlo >> s) & 1u) | (((qhi >> s) & 1u) << 1);
+        S.sel[s] = 0x0C0C0C00u | (((qn >> s) & 1u) ? 4u : idx);
+    }
+}
+
+// one DP row; returns the lane's row maximum (NEG when none of its cells is live)
+template <bool EDGE>
+__device__ __forceinline__ int32_t lean_row(LeanState &S, uint32_t srow, int32_t O, int32_t E, int32_t thr, uint32_t exmask,
+                                            int32_t lane_base, int32_t kneg128) {
+    const int32_t OE = O + E;
+    // C of the column left of my strip (previous row): last slot of the previous lane
+    PCell pc = dpp_pcell<0x138, 0xf>(PCell{S.C[L_WS - 1], S.Cc[L_WS - 1]});
+    // pass 1 (slots descending, in place): D and H = max(diagonal, D); slot s still sees the old C of slot s - 1
+#pragma unroll
+    for (int s = L_WS - 1; s >= 0; s--) {
+        const int32_t t1 = S.D[s] - E, t2 = S.C[s] - OE;
+        const bool open = t2 > t1;
+        const int32_t ds = max(t1, t2);
+        const uint32_t dc = open ? S.Cc[s] : S.Dc[s];
+        const PCell left = s ? PCell{S.C[s ? s - 1 : 0], S.Cc[s ? s - 1 : 0]} : pc;
+        const uint32_t scb = __builtin_amdgcn_perm(28u, srow, S.sel[s]);   // score + 128
+        const int32_t gs = left.s + (int32_t)scb + kneg128;
+        const uint32_t gc = left.c + 0x10000u + ((int32_t)scb > 128 ? 1u : 0u);   // diagonal steps << 16 | matches
+        const bool vert = ds > gs;  // diagonal preferred on ties
+        S.D[s] = ds; S.Dc[s] = dc;
+        S.C[s] = max(gs, ds);
+        S.Cc[s] = vert ? dc : gc;
+    }
+    // pass 2: the strip's aggregate of the insertion state as it arrives at the first column of the next strip
+    PCell run{NEG, 0};
+#pragma unroll
+    for (int s = 0; s < L_WS; s++) {
+        const bool take = S.C[s] > run.s;  // ties -> left
+        run.c = take ? S.Cc[s] : run.c;
+        run.s = max(run.s, S.C[s]) - E;
+    }
+    run.s += lane_base;  // common frame: column 0 of the window
+    PCell acc = dpp_pcell<0x138, 0xf>(lean_incl_maxscan(run));  // best of every column left of my strip
+    acc.s += 16 * E - lane_base;                                   // ... as it arrives at my first column
+    // pass 3: C = max(H, I), prune, row maximum
+    int32_t rowmax = NEG;
+#pragma unroll
+    for (int s = 0; s < L_WS; s++) {
+        const int32_t hs = S.C[s];
+        const uint32_t hc = S.Cc[s];
+        const int32_t is = acc.s - O;
+        const bool ins = is > hs;       // H preferred over I on ties
+        const int32_t cs = max(hs, is);
+        const uint32_t cc = ins ? acc.c : hc;
+        const bool take = hs > acc.s;   // ties -> left
+        acc.c = take ? hc : acc.c;
+        acc.s = max(acc.s, hs) - E;
+        bool alive = cs >= thr;
+        if (EDGE) alive = alive && ((exmask >> s) & 1u);
+        S.C[s] = alive ? cs : NEG; S.Cc[s] = cc;
+        S.D[s] = alive ? S.D[s] : NEG;
+        rowmax = max(rowmax, S.C[s]);
+    }
+    return rowmax;
+}
+
+__device__ HalfResult wave_half_extend_lean(const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq, int dir,
+                                            int32_t O, int32_t E, int32_t Y) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
+    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- exact shortcut: identical, N-free to the end of the shorter sequence (as wave_half_extend)
+    {
+        const uint32_t n = min(lenA, lenB);
+        const int32_t st = dir > 0 ? (int32_t)at : (int32_t)(at - n), sq = dir > 0 ? (int32_t)aq : (int32_t)(aq - n);
+        bool ok = true;
+        uint64_t ncg = 0;
+        for (uint32_t k0 = 0; k0 < n; k0 += 64u * 32u) {
+            uint32_t k = k0 + lane * 32u;
+            if (k < n) {
+                const Win32 tw = win32(T, st + (int32_t)k), qw = win32(Q, sq + (int32_t)k);
+                uint32_t bad = (tw.lo ^ qw.lo) | (tw.hi ^ qw.hi) | tw.nm | qw.nm;
+                uint32_t rem = n - k, mask = rem < 32 ? (1u << rem) - 1u : 0xFFFFFFFFu;
+                if (bad & mask) ok = false;
+                ncg += __popc((tw.lo ^ tw.hi) & mask);
+            }
+            if (__ballot(!ok)) break;
+        }
+        if (!__ballot(!ok)) {
+            for (int o = 32; o > 0; o >>= 1) ncg += __shfl_xor(ncg, o);
+            uint64_t sc = 100ull * ncg + 91ull * ((uint64_t)n - ncg);
+            best.score = (int32_t)(uint32_t)sc; best.maxcols = (uint32_t)(sc >> 32); best.i = n; best.j = n; best.nm = n; best.nx = 0;
+            return best;
+        }
+    }
+    // biased score bytes of the four query bases for each target base (index lo | hi << 1)
+    uint32_t tab[4];
+#pragma unroll
+    for (uint32_t a = 0; a < 4; a++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t alo = a & 1u, ahi = a >> 1, dl = alo ^ (b & 1u), dh = ahi ^ (b >> 1);
+            w |= (uint32_t)(sub_score(dl, dh, alo ^ ahi, 0u) + 128) << (8u * b);
+        }
+        tab[a] = w;
+    }
+    LeanState S;
+    uint32_t wb = 0, jb = lane * L_WS;
+    {
+        uint32_t qlo, qhi, qn;
+        load_qbits<L_WS>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+        lean_selectors(S, qlo, qhi, qn);
+    }
+    bool over = false;
+#pragma unroll
+    for (int s = 0; s < L_WS; s++) {
+        const uint32_t j = jb + s;
+        const int32_t v = j ? -O - (int32_t)j * E : 0;
+        const bool alive = j <= lenB && (j == 0 || v >= -Y);
+        S.C[s] = alive ? v : NEG; S.Cc[s] = 0;
+        S.D[s] = NEG; S.Dc[s] = 0;
+        if (alive && j >= (uint32_t)(L_WINDOW - L_WS)) over = true;
+    }
+    if (__ballot(over)) { best.overflow = 1; return best; }
+    const int32_t lane_base = (int32_t)(lane * L_WS) * E;
+    const int32_t kneg128 = __builtin_amdgcn_readfirstlane(-128);
+    uint32_t exmask = 0xFFFFu;
+    bool edge = wb + (uint32_t)L_WINDOW - 1u > lenB;
+    if (edge) {
+        exmask = 0;
+#pragma unroll
+        for (int s = 0; s < L_WS; s++) exmask |= (jb + s <= lenB ? 1u : 0u) << s;
+    }
+    RowBases rbase{0, 0, 0}, rnext = load_row_bases(T, at, dir, 1u);
+    for (uint32_t i = 1; i <= lenA; i++) {
+        // the packed counts hold 16 bits each: a longer extension is redone by the wide kernel (unpacked counts)
+        if (i >= 0xFFFFu) { best.overflow = 1; break; }
+        const int32_t thr = best.score - Y;
+        const uint32_t rbit = (i - 1u) & 31u;
+        if (rbit == 0) { rbase = rnext; rnext = load_row_bases(T, at, dir, i + 32u); }
+        const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase.lo), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase.hi),
+                       rnm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rbase.nm);
+        const uint32_t a = ((rlo >> rbit) & 1u) | (((rhi >> rbit) & 1u) << 1);
+        uint32_t srow = a & 2u ? (a & 1u ? tab[3] : tab[2]) : (a & 1u ? tab[1] : tab[0]);
+        if ((rnm >> rbit) & 1u) srow = 0x1C1C1C1Cu;
+        const int32_t rowmax = edge ? lean_row<true>(S, srow, O, E, thr, exmask, lane_base, kneg128)
+                                    : lean_row<false>(S, srow, O, E, thr, exmask, lane_base, kneg128);
+        const uint64_t ball = __ballot(rowmax > NEGH);
+        if (!ball) break;
+        const uint32_t rf = (uint32_t)__builtin_ctzll(ball), rl = 63u - (uint32_t)__builtin_clzll(ball);
+        if (rl == 63u) { best.overflow = 1; break; }
+        best.maxcols = max(best.maxcols, (rl + 1u) * L_WS);
+        best.rows = i;
+        const int32_t wmax = wave_max_i32(rowmax);
+        if (wmax > best.score) {
+            // the cell: lowest lane holding the maximum, smallest slot in it (smallest column on ties)
+            const uint32_t L = (uint32_t)__builtin_ctzll(__ballot(rowmax == wmax));
+            uint32_t slot = 0, cnt = 0;
+#pragma unroll
+            for (int s = L_WS - 1; s >= 0; s--) {
+                const int32_t v = __builtin_amdgcn_readlane(S.C[s], (int)L);
+                if (v == wmax) { slot = (uint32_t)s; cnt = (uint32_t)__builtin_amdgcn_readlane((int)S.Cc[s], (int)L); }
+            }
+            best.score = wmax; best.i = i; best.j = wb + L * L_WS + slot; best.nm = cnt & 0xFFFFu; best.nx = (cnt >> 16) - (cnt & 0xFFFFu);
+        }
+        // slide the window so that it starts at the strip holding the first live column
+        if (rf) {
+            wb += rf * L_WS;
+            jb = wb + lane * L_WS;
+            const int src = (int)((lane + rf) & 63u);
+            const bool fresh = lane + rf >= 64u;  // strip re-enters on the right with new columns
+#pragma unroll
+            for (int s = 0; s < L_WS; s++) {
+                const int32_t cs = __shfl(S.C[s], src), ds = __shfl(S.D[s], src);
+                S.Cc[s] = __shfl(S.Cc[s], src); S.Dc[s] = __shfl(S.Dc[s], src);
+                S.sel[s] = __shfl(S.sel[s], src);
+                S.C[s] = fresh ? NEG : cs;
+                S.D[s] = fresh ? NEG : ds;
+            }
+            if (fresh) {
+                uint32_t qlo, qhi, qn;
+                load_qbits<L_WS>(Q, aq, dir, jb, lenB, qlo, qhi, qn);
+                lean_selectors(S, qlo, qhi, qn);
+            }
+            edge = wb + (uint32_t)L_WINDOW - 1u > lenB;
+            if (edge) {
+                exmask = 0;
+#pragma unroll
+                for (int s = 0; s < L_WS; s++) exmask |= (jb + s <= lenB ? 1u : 0u) << s;
+            }
+        }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(64) void k6_dp1(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
+                                             HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
+    const DpJob job = jobs[blockIdx.x];
+    const Group &G = groups[job.group];
+    HalfResult r = wave_half_extend_lean(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    if (threadIdx.x == 0) res[job.slot] = r;
+}
+
 __global__ __launch_bounds__(C4_THREADS) void k6_dp4(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                                      HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y) {
     __shared__ C4Shared sh;
@@ -982,13 +1238,22 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
             HIP_TRY(hipMemcpyAsync(h, g_cnt.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (h[0]) {
-                static int dp4_max = getenv("MIMEO_K6_DP4_MAX") ? atoi(getenv("MIMEO_K6_DP4_MAX")) : 1 << 30;
-                const bool use4 = (int)h[0] <= dp4_max;  // measured faster in both regimes (C2: 150 -> 126 ms; 1/8 shard: 59 -> 42 ms)
-                if (use4)
-                    hipLaunchKernelGGL(k6_dp4, dim3(h[0]), dim3(C4_THREADS), 0, st, (const Group *)d_groups,
-                                       (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
-                hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
-                                   (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0);
+                // MIMEO_K6_KERNEL (development A/B): "dp4" = the four-wavefront kernel then wave_half_extend<16>, "dp" = the
+                // latter alone; default = the lean single-wavefront kernel (its dead-cell arithmetic needs the
+                // penalties to stay far below 2^29 / 1024)
+                const char *kmode = getenv("MIMEO_K6_KERNEL");
+                const bool lean_ok = p->gap_extend <= (1 << 16) && p->gap_open <= (1 << 24) && p->ydrop <= (1 << 28);
+                if (lean_ok && !kmode) {
+                    hipLaunchKernelGGL(k6_dp1, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
+                                       (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+                } else {
+                    const bool use4 = !kmode || !strcmp(kmode, "dp4");
+                    if (use4)
+                        hipLaunchKernelGGL(k6_dp4, dim3(h[0]), dim3(C4_THREADS), 0, st, (const Group *)d_groups,
+                                           (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
+                    hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
+                                       (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0);
+                }
                 hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
                                    (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, novf,
                                    (unsigned int *)g_ovf_list.p);
