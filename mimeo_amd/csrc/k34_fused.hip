@@ -47,25 +47,27 @@ struct FusedArgs {
 };
 
 // ---- pre-filter on two frames in the common alignment ------------------------------------------------------
-// left walk = frame bits 127 .. 32 (six 16-step blocks), right walk = bits 128 .. 191 (four blocks); the seed windows
+// left walk = frame bits 127 .. 32 (four 24-step blocks), right walk = bits 128 .. 191 (24 + 24 + 16); the seed windows
 // that END where left step s arrives start at bit 108 - s.  A pair is dismissed when (i) both walks provably stop
 // inside the frame, (ii) no earlier seed hit of the diagonal can end at a boundary the left walk reaches before its
 // proven stop, so the hit is a head, and (iii) an upper bound of best(left) + best(right) is below hspthresh: the exact
 // walk would then find an isolated head that scores too little, and emit nothing.  Everything else goes to the batch's
 // walk queue (k4_walk_queue: the exact walk).  The proofs use the CHEAP bounds — two popcounts per block: n =
 // mismatching columns, v = transversions; a match scores 91..100, a transition -31, a transversion -125..-114 — and
-// a seed test on ten of the twelve care positions without the transition rule: 3.8 % of random hits are walked
-// instead of 1.4 % with the sharpest bounds, for 40 % fewer instructions per pair (scripts/dev_filter_mc.py; the
+// a seed test on ten of the twelve care positions without the transition rule: 4.1 % of random hits are walked
+// instead of 1.4 % with the sharpest bounds, for half the instructions per pair (scripts/dev_filter_mc.py; the
 // kernel is bound by VALU issue, and popcounts, funnel shifts, compares and max issue at half rate).
 struct Bound2 {
     int32_t up, lomax, ub;   // upper bound of the prefix score; best lower bound at an earlier checkpoint; bound of the best prefix
     bool stop;
 };
-__device__ __forceinline__ void bound_block2(Bound2 &B, uint32_t v16, uint32_t n16, int32_t &lo, int xdrop) {
-    const int32_t pv = __popc(v16), pn = __popc(n16);
-    B.ub = max(B.ub, B.up + 1600 - 100 * pn);
-    B.up += 1600 - 131 * pn - 83 * pv;
-    lo += 1456 - 122 * pn - 94 * pv;
+// one block of W columns: v = its transversion bits, n = its mismatch bits
+template <int W>
+__device__ __forceinline__ void bound_block2(Bound2 &B, uint32_t v, uint32_t n, int32_t &lo, int xdrop) {
+    const int32_t pv = __popc(v), pn = __popc(n);
+    B.ub = max(B.ub, B.up + 100 * W - 100 * pn);
+    B.up += 100 * W - 131 * pn - 83 * pv;
+    lo += 91 * W - 122 * pn - 94 * pv;
     B.stop = B.stop || (B.up + xdrop < B.lomax);
     B.lomax = max(B.lomax, lo);
 }
@@ -87,7 +89,9 @@ __device__ __forceinline__ uint32_t seed_starts32(uint32_t n0, uint32_t n1, uint
     return ~(transitions ? (twos | tv) : ones);
 }
 
-// true = the pair is walked exactly
+// true = the pair is walked exactly.  Blocks of 24 columns (left: four, right: 24 + 24 + 16): seven blocks instead of
+// the ten 16-column ones pass 4.1 % of random hits on instead of 3.8 % (scripts/dev_filter_mc.py) for 15 % fewer
+// instructions per pair.
 __device__ __forceinline__ bool pair_needs_walk(const uint4 t0, const uint4 t1, const uint4 t2, const uint4 q0, const uint4 q1,
                                                 const uint4 q2, int xdrop, int hspthresh, int transitions) {
     // planes: lo = {0.x 0.y 0.z 0.w 1.x 1.y}, hi = {1.z 1.w 2.x 2.y 2.z 2.w}
@@ -100,18 +104,21 @@ __device__ __forceinline__ bool pair_needs_walk(const uint4 t0, const uint4 t1, 
     const uint32_t h2 = seed_starts32<CARE10, false>(n0, n1, 0u, 0u, transitions);   // bit 95 - s  <-> step s      (s = 64..95)
     Bound2 L{0, 0, 0, false}, R{0, 0, 0, false};
     int32_t llo = 0, rlo = 0;
-    uint32_t veto = 0;
-    // a boundary only counts while the walk is not yet proven to have stopped
-    veto |= h0 >> 16;                        bound_block2(L, dl3 >> 16, n3 >> 16, llo, xdrop);
-    veto |= L.stop ? 0u : (h0 & 0xFFFFu);    bound_block2(L, dl3 & 0xFFFFu, n3 & 0xFFFFu, llo, xdrop);
-    veto |= L.stop ? 0u : (h1 >> 16);        bound_block2(L, dl2 >> 16, n2 >> 16, llo, xdrop);
-    veto |= L.stop ? 0u : (h1 & 0xFFFFu);    bound_block2(L, dl2 & 0xFFFFu, n2 & 0xFFFFu, llo, xdrop);
-    veto |= L.stop ? 0u : (h2 >> 16);        bound_block2(L, dl1 >> 16, n1 >> 16, llo, xdrop);
-    veto |= L.stop ? 0u : (h2 & 0xFFFFu);    bound_block2(L, dl1 & 0xFFFFu, n1 & 0xFFFFu, llo, xdrop);
-    bound_block2(R, dl4 & 0xFFFFu, n4 & 0xFFFFu, rlo, xdrop);
-    bound_block2(R, dl4 >> 16, n4 >> 16, rlo, xdrop);
-    bound_block2(R, dl5 & 0xFFFFu, n5 & 0xFFFFu, rlo, xdrop);
-    bound_block2(R, dl5 >> 16, n5 >> 16, rlo, xdrop);
+    uint32_t veto;
+    constexpr uint32_t M24 = 0xFFFFFFu;
+    // left walk: columns 127 downwards; a boundary only counts while the walk is not yet proven to have stopped
+    veto = h0 >> 8;                                                   // steps 0 .. 23
+    bound_block2<24>(L, dl3 >> 8, n3 >> 8, llo, xdrop);                                                               // columns 104 .. 127
+    veto |= L.stop ? 0u : ((h0 & 0xFFu) | (h1 >> 16));                // steps 24 .. 47
+    bound_block2<24>(L, __builtin_amdgcn_alignbit(dl3, dl2, 16) & M24, __builtin_amdgcn_alignbit(n3, n2, 16) & M24, llo, xdrop);   // 80 .. 103
+    veto |= L.stop ? 0u : ((h1 & 0xFFFFu) | (h2 >> 24));              // steps 48 .. 71
+    bound_block2<24>(L, __builtin_amdgcn_alignbit(dl2, dl1, 24) & M24, __builtin_amdgcn_alignbit(n2, n1, 24) & M24, llo, xdrop);   // 56 .. 79
+    veto |= L.stop ? 0u : (h2 & M24);                                 // steps 72 .. 95
+    bound_block2<24>(L, dl1 & M24, n1 & M24, llo, xdrop);                                                              // 32 .. 55
+    // right walk: columns 128 upwards
+    bound_block2<24>(R, dl4 & M24, n4 & M24, rlo, xdrop);                                                              // 128 .. 151
+    bound_block2<24>(R, __builtin_amdgcn_alignbit(dl5, dl4, 24) & M24, __builtin_amdgcn_alignbit(n5, n4, 24) & M24, rlo, xdrop);   // 152 .. 175
+    bound_block2<16>(R, dl5 >> 16, n5 >> 16, rlo, xdrop);                                                              // 176 .. 191
     return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
 }
 

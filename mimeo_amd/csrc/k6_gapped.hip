@@ -547,8 +547,10 @@ __device__ HalfResult block_half_extend(C4Shared &sh, const StrandView &T, const
 //     all the window slide and the overflow test ever needed;
 //   * columns beyond the end of the query only exist when the window touches it: rows of such windows run the
 //     EDGE variant (one extra mask test per cell), selected wave-uniformly.
-// ~28 VALU instructions per cell, ~520 per row.
-constexpr int L_WS = 16, L_WINDOW = 64 * L_WS;
+// Measured: ~40 VALU instructions per cell.  Strips of 14 columns (896-column window): the widest live band of a
+// default-parameter extension is ~600 + 2 strips (y-drop 9400 / gap extend 30 on either side of the best cell; C4: all
+// below 768), and a band that does not fit is redone by the 2048-column kernel.
+constexpr int L_WS = 14, L_WINDOW = 64 * L_WS;
 struct LeanState {
     int32_t C[L_WS], D[L_WS];
     uint32_t Cc[L_WS], Dc[L_WS], sel[L_WS];
@@ -624,7 +626,7 @@ __device__ __forceinline__ int32_t lean_row(LeanState &S, uint32_t srow, int32_t
     }
     run.s += lane_base;  // common frame: column 0 of the window
     PCell acc = dpp_pcell<0x138, 0xf>(lean_incl_maxscan(run));  // best of every column left of my strip
-    acc.s += 16 * E - lane_base;                                   // ... as it arrives at my first column
+    acc.s += L_WS * E - lane_base;                                   // ... as it arrives at my first column
     // pass 3: C = max(H, I), prune, row maximum
     int32_t rowmax = NEG;
 #pragma unroll
@@ -708,7 +710,7 @@ __device__ HalfResult wave_half_extend_lean(const StrandView &T, const StrandVie
     if (__ballot(over)) { best.overflow = 1; return best; }
     const int32_t lane_base = (int32_t)(lane * L_WS) * E;
     const int32_t kneg128 = __builtin_amdgcn_readfirstlane(-128);
-    uint32_t exmask = 0xFFFFu;
+    uint32_t exmask = (1u << L_WS) - 1u;
     bool edge = wb + (uint32_t)L_WINDOW - 1u > lenB;
     if (edge) {
         exmask = 0;
@@ -1213,7 +1215,8 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
     if (!p->gapped) {
         hipLaunchKernelGGL(k6_ungapped, dim3(ngroups), dim3(256), 0, st, d_groups, d_sorted, d_order, d_aln);
     } else {
-        uint32_t bmax = 4096u / ngroups;
+        uint32_t bmax = 8192u / ngroups;  // anchors per group and round (200 units: 32 -> one large round and a short one)
+        if (getenv("MIMEO_K6_BMAX")) bmax = (uint32_t)atoi(getenv("MIMEO_K6_BMAX"));
         bmax = bmax < 1 ? 1 : (bmax > MAX_BATCH ? MAX_BATCH : bmax);
         if ((rc = g_anchors.reserve(nhsps * sizeof(uint2)))) return rc;
         if ((rc = g_packed.reserve(nhsps * 8))) return rc;
@@ -1285,6 +1288,13 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                 fprintf(stderr, "[k6] jobs %u shortcut %llu rows total %llu max %llu band<128..>=1024:", h[0], shortcut, rows, maxr);
                 for (int b = 0; b < 9; b++) fprintf(stderr, " %llu", hist[b]);
                 fprintf(stderr, "\n");
+                {
+                    unsigned long long fine[34] = {0};
+                    for (auto &r : hr) if (r.rows) fine[std::min<uint32_t>(33, r.maxcols / 32)]++;
+                    fprintf(stderr, "[k6] widest band, buckets of 32 columns from 448:");
+                    for (int b = 14; b < 34; b++) fprintf(stderr, " %llu", fine[b]);
+                    fprintf(stderr, "\n");
+                }
                 int shown = 0;
                 for (auto &r : hr)
                     if (!r.rows && shown < 8) { fprintf(stderr, "  [k6] zero-row job: score %d i %u j %u nm %u nx %u ovf %u\n", r.score, r.i, r.j, r.nm, r.nx, r.overflow); shown++; }
