@@ -215,6 +215,8 @@ int chain_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, con
 // d_aln[hsp_begin .. hsp_begin + naln)
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln);
+// alignments of all groups packed densely (group g: d_dense[job0 .. job0 + naln)); same stream as gapped_device
+void dense_alignments_device(Group *d_groups, uint32_t ngroups, const mimeo_alignment *d_aln, mimeo_alignment *d_dense);
 // chain + gapped extension of every group (pipeline.hip)
 int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
                         const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,

@@ -1205,6 +1205,39 @@ __global__ void k6_finish(Group *__restrict__ groups, uint32_t ngroups, mimeo_al
     G.naln = k;
 }
 
+// The alignments of group g sit at d_aln[hsp_begin .. hsp_begin + naln): a few thousand records scattered over an array of
+// one slot per HSP (70 MB on a C4 row).  Packed densely before the read-back: job0 = the group's first dense slot.
+__global__ __launch_bounds__(1024) void k6_dense_offsets(Group *__restrict__ groups, uint32_t ngroups) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 1024) {
+        const uint32_t g = g0 + threadIdx.x, n = g < ngroups ? groups[g].naln : 0u;
+        part[threadIdx.x] = n;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (g < ngroups) groups[g].job0 = carry + part[threadIdx.x] - n;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64) void k6_dense_copy(const Group *__restrict__ groups, const mimeo_alignment *__restrict__ aln,
+                                                    mimeo_alignment *__restrict__ dense) {
+    const Group &G = groups[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < G.naln; k += 64) dense[G.job0 + k] = aln[G.hsp_begin + k];
+}
+void dense_alignments_device(Group *d_groups, uint32_t ngroups, const mimeo_alignment *d_aln, mimeo_alignment *d_dense) {
+    hipLaunchKernelGGL(k6_dense_offsets, dim3(1), dim3(1024), 0, stream(), d_groups, ngroups);
+    hipLaunchKernelGGL(k6_dense_copy, dim3(ngroups), dim3(64), 0, stream(), (const Group *)d_groups, d_aln, d_dense);
+}
+
 static DeviceBuf g_anchors, g_packed, g_jobs, g_res, g_cnt, g_astate, g_ovf_list, g_any;
 
 int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, const uint32_t *d_order,

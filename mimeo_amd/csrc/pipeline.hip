@@ -89,7 +89,7 @@ struct IndexCache {
 };
 
 static ExtBatch g_ext;
-static DeviceBuf g_scratch, g_aln, g_groups;
+static DeviceBuf g_scratch, g_aln, g_dense, g_groups;
 
 struct Unit {
     uint64_t pair;  // index into pair_t / pair_q
@@ -101,6 +101,7 @@ void release_pipeline_buffers() {
     g_ext.release();
     g_scratch.release();
     g_aln.release();
+    g_dense.release();
     g_groups.release();
 }
 
@@ -253,10 +254,19 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                                               (const uint32_t *)g_ext.hsp_unit.p, nh, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain,
                                               &ms_gapped)))
                     break;
-                std::vector<mimeo_alignment> host_aln(nh);
+                // the alignments are a few thousand records in an array of one slot per HSP: packed on the device, then read
+                if ((rc = g_dense.reserve(nh * sizeof(mimeo_alignment)))) break;
+                dense_alignments_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_alignment *)g_aln.p,
+                                        (mimeo_alignment *)g_dense.p);
                 if (hipMemcpyAsync(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipMemcpyAsync(host_aln.data(), g_aln.p, nh * sizeof(mimeo_alignment), hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess) {
+                    set_error("HIP error while reading back alignments");
+                    rc = MIMEO_ERR_HIP;
+                    break;
+                }
+                const uint64_t naln_total = (uint64_t)groups.back().job0 + groups.back().naln;
+                std::vector<mimeo_alignment> host_aln(naln_total);
+                if (naln_total && hipMemcpy(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost) != hipSuccess) {
                     set_error("HIP error while reading back alignments");
                     rc = MIMEO_ERR_HIP;
                     break;
@@ -276,7 +286,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
                     }
                     g_stats.chained_hsps += g.nchain;
                     auto &dst = per_pair[units[b0 + gi].pair];
-                    dst.insert(dst.end(), host_aln.begin() + g.hsp_begin, host_aln.begin() + g.hsp_begin + g.naln);
+                    dst.insert(dst.end(), host_aln.begin() + g.job0, host_aln.begin() + g.job0 + g.naln);
                 }
             }
             if (timing) {
