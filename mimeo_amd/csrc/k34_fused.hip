@@ -21,16 +21,17 @@
 // HBM traffic per unit: the two offset arrays, and positions + frames of both sides ONCE (52 bytes per entry).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "k4_device.h"
 
 namespace mimeo {
 
 constexpr uint32_t TCH = 64;      // target entries per wavefront and chunk: one per lane
-constexpr uint32_t DQ = 256;      // pair descriptors per wavefront and round
+constexpr uint32_t DQ = 192;      // pair descriptors per wavefront and round
 constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CARE19
 constexpr unsigned long long HEAVY_HITS = 262144;   // hits of a tile beyond which it is split (a tile of a 10 Mbp x 10 Mbp unit averages 19 000)
-constexpr uint32_t HEAVY_MAX = 64;     // listed tiles per unit = grid of the split pass (further ones are done unsplit by the first pass)
+constexpr uint32_t HEAVY_MAX = 64;     // x extent of the split pass grid: its workgroups loop over the listed tiles
 constexpr uint32_t HEAVY_SPLIT = 8, HEAVY_QSPLIT = 8;   // ... over 8 shares of its target chunks x 8 shares of its query segments
 
 struct FusedArgs {
@@ -128,95 +129,41 @@ __device__ __forceinline__ uint4 bperm4(uint32_t src_lane, const uint4 v) {
                       (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.z), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.w));
 }
 
-template <int THREADS, uint32_t QSEG>
+// LDS of a workgroup: the query tile's offsets (relative to its first entry: 16 bits each in the first pass, which
+// leaves tiles of 65536 query entries and more to the split pass), QSEG query frames (three 16-byte parts), one
+// descriptor queue and one walk staging area per wavefront, the N flags of the segment.  First pass: 512 threads, two
+// workgroups per CU, QSEG = 1280 (79 KiB each): the 2441 entries of an average C4 tile are two segments — every target
+// chunk is visited once per segment (frames, key, 13 probes, prefix sum, descriptors: ~530 instructions for the
+// visit), so three segments of 1024 cost a third more visits for the same pairs.
+template <int THREADS, uint32_t QSEG, bool HEAVY>
 struct FusedCfg {
     static constexpr int WAVES = THREADS / 64;
-    static constexpr size_t SMEM = (TILE_WORDS + 4) * 4 + (size_t)QSEG * 48 + (size_t)WAVES * DQ * 4 + (size_t)WAVES * 64 * 8 + QSEG + 16;
+    static constexpr size_t OFF_BYTES = ((TILE_WORDS + 1) * (HEAVY ? 4 : 2) + 15) / 16 * 16;
+    static constexpr size_t SMEM = OFF_BYTES + (size_t)QSEG * 48 + (size_t)WAVES * DQ * 4 + (size_t)WAVES * 64 * 8 + QSEG + 16;
 };
 
-template <int THREADS, uint32_t QSEG>
-__global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3 : (QSEG > 1024 ? 2 : 4)))) void k34_scan_extend(FusedArgs A) {
+// HEAVY = the split pass: the workgroups (x) loop over the tiles the first pass listed, y = share of a tile's target
+// chunks, z = share of its query segments; 32-bit offsets.
+template <int THREADS, uint32_t QSEG, bool HEAVY>
+__global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
+    using Cfg = FusedCfg<THREADS, QSEG, HEAVY>;
+    using qoff_t = typename std::conditional<HEAVY, uint32_t, uint16_t>::type;
     constexpr int WAVES = THREADS / 64;
+    static_assert((size_t)QSEG * 48 >= 2 * (TILE_WORDS + 4) * 4, "the count prologue stages both offset arrays in the frame area");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *sQ = reinterpret_cast<uint32_t *>(smem);                                  // TILE_WORDS + 4
-    uint4 *sQF = reinterpret_cast<uint4 *>(smem + (TILE_WORDS + 4) * 4);                 // 3 parts of QSEG
+    qoff_t *sQ = reinterpret_cast<qoff_t *>(smem);                                      // TILE_WORDS + 1
+    uint4 *sQF = reinterpret_cast<uint4 *>(smem + Cfg::OFF_BYTES);                       // 3 parts of QSEG
     uint32_t *sD_all = reinterpret_cast<uint32_t *>(sQF + QSEG * 3);                     // WAVES * DQ
     uint2 *s_walk_all = reinterpret_cast<uint2 *>(sD_all + WAVES * DQ);                  // WAVES * 64
     uint8_t *sQN = reinterpret_cast<uint8_t *>(s_walk_all + WAVES * 64);                 // QSEG
     unsigned long long *s_total = reinterpret_cast<unsigned long long *>(sQN + QSEG);
+    __shared__ unsigned long long s_slot;
 
-    // A tile with far more hits than the average (a microsatellite's seed words: thousands of entries of ONE key on both
-    // sides, 10^7-10^8 hits in one tile) is not worked off by one workgroup while the chip waits: the first pass lists it,
-    // the second pass (grid = listed tiles x HEAVY_SPLIT x HEAVY_QSPLIT) cuts its target chunks and its query segments
-    // over that many workgroups.
-    uint32_t tile = blockIdx.x;
-    if (A.heavy_pass) {
-        const uint32_t nlist = (uint32_t)min((unsigned long long)HEAVY_MAX, A.q.ctr->nheavy);
-        if (blockIdx.x + A.heavy_base >= nlist) return;
-        tile = A.q.heavy[blockIdx.x + A.heavy_base];
-    }
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t t0 = A.T.off[(size_t)tile * TILE_WORDS], nT = A.T.off[(size_t)tile * TILE_WORDS + TILE_WORDS] - t0;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(A.Q.off + (size_t)tile * TILE_WORDS);
-        uint4 *dst = reinterpret_cast<uint4 *>(sQ);
-        for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += THREADS) dst[k] = src[k];
-        if (threadIdx.x == 0) { sQ[TILE_WORDS] = A.Q.off[(size_t)tile * TILE_WORDS + TILE_WORDS]; *s_total = 0ull; }
-    }
-    __syncthreads();
-    const uint32_t q0 = sQ[0], nQ = sQ[TILE_WORDS] - q0;
-    if (!nT || !nQ) {
-        if (threadIdx.x == 0 && !A.heavy_pass) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
-        return;
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] -= q0;   // offsets relative to the tile's first query entry
-    const bool single = nQ <= QSEG;   // the whole query tile in one segment: no clipping of the neighbour ranges
-    if (A.heavy_pass && blockIdx.z * QSEG >= nQ) return;   // no query segment for this share (uniform: before any further barrier)
-    if (!A.heavy_pass) {
-        // The tile's hit count up front (K3's counting pass, per tile: the target offsets pass through the frame area of
-        // LDS once): it is the statistic, and a tile with far more hits than the average is left to the split pass.
-        __syncthreads();
-        uint32_t *sT = reinterpret_cast<uint32_t *>(sQF);
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(A.T.off + (size_t)tile * TILE_WORDS);
-            uint4 *dst = reinterpret_cast<uint4 *>(sT);
-            for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += THREADS) dst[k] = src[k];
-            if (threadIdx.x == 0) sT[TILE_WORDS] = t0 + nT;
-        }
-        __syncthreads();
-        unsigned long long cnt = 0;
-        for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS) {
-            const uint32_t nt = sT[w + 1] - sT[w];
-            if (nt) {
-                uint32_t sum = sQ[w + 1] - sQ[w];
-                if (A.transitions)
-                    for (int j = 0; j < SEED_WEIGHT; j++) { const uint32_t w2 = w ^ (1u << j); sum += sQ[w2 + 1] - sQ[w2]; }
-                cnt += (unsigned long long)nt * sum;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (lane == 0 && cnt) atomicAdd(s_total, cnt);
-        __syncthreads();
-        const unsigned long long tile_total = *s_total;
-        if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = tile_total;
-        if (tile_total > HEAVY_HITS) {
-            __shared__ unsigned long long s_slot;
-            if (threadIdx.x == 0) {
-                s_slot = atomicAdd(&A.q.ctr->nheavy, 1ull);
-                if (s_slot < HEAVY_MAX) A.q.heavy[s_slot] = tile;
-            }
-            __syncthreads();
-            if (s_slot < HEAVY_MAX) return;   // the split pass does this tile (beyond the list's capacity: this workgroup does, after all)
-        }
-        if (!tile_total) return;
-        __syncthreads();
-    }
     uint32_t *sD = sD_all + wv * DQ;
     uint2 *s_walk = s_walk_all + wv * 64;
     uint32_t n_walk = 0;
-    const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
 
     // the pairs the filter passed on go to the batch's walk queue, 64 at a time (one atomic per flush)
     auto flush_walk = [&](uint32_t n) {
@@ -229,122 +176,186 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : (THREADS == 768 ? 3
         __builtin_amdgcn_wave_barrier();
     };
 
-    const uint32_t nchunks = (nT + TCH - 1) / TCH;
-    // chunks of this workgroup: every one (first pass), or those of my share of the tile (heavy pass)
-    const uint32_t ch_first = (A.heavy_pass ? blockIdx.y * WAVES : 0u) + wv, ch_step = (A.heavy_pass ? gridDim.y : 1u) * WAVES;
-    // my first chunk's frames (one entry per lane): in flight while the first query segment is staged
-    uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = nf0, nf2 = nf0;
-    uint32_t npos = 0;
-    if (ch_first < nchunks) {
-        const uint32_t e = ch_first * TCH + lane;
-        if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
-    }
-    const uint32_t qs_first = A.heavy_pass ? blockIdx.z * QSEG : 0u, qs_step = (A.heavy_pass ? gridDim.z : 1u) * QSEG;
-    for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
-        const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
-        __syncthreads();  // every wavefront is through with the previous segment
-        {
-            const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
-            for (uint32_t i = threadIdx.x; i < qn; i += THREADS) {
-                sQF[i] = s0[i];
-                sQF[QSEG + i] = s1[i];
-                sQF[2 * QSEG + i] = s2[i];
-                sQN[i] = (uint8_t)(A.Q.pos[q0 + qs + i] >> 31);
+    // everything below returns for the whole workgroup at once (the conditions are uniform)
+    auto do_tile = [&](const uint32_t tile) {
+        const uint32_t *toff = A.T.off + (size_t)tile * TILE_WORDS, *qoff = A.Q.off + (size_t)tile * TILE_WORDS;
+        const uint32_t t0 = toff[0], nT = toff[TILE_WORDS] - t0;
+        const uint32_t q0 = qoff[0], nQ = qoff[TILE_WORDS] - q0;
+        if (!nT || !nQ) {
+            if (threadIdx.x == 0 && !HEAVY) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
+            return;
+        }
+        if (HEAVY && blockIdx.z * QSEG >= nQ) return;   // no query segment for this share
+        if (!HEAVY) {
+            // The tile's hit count up front (K3's counting pass, per tile: both offset arrays pass through the frame area of
+            // LDS once): it is the statistic, and a tile with far more hits than the average — a microsatellite's seed
+            // words: thousands of entries of ONE key on both sides, 10^7-10^8 hits in one tile — or with more query entries
+            // than 16-bit offsets can name is not worked off by one workgroup while the chip waits: it is listed for the
+            // split pass.
+            uint32_t *sT = reinterpret_cast<uint32_t *>(sQF), *sQ32 = sT + TILE_WORDS + 4;
+            {
+                const uint4 *s0 = reinterpret_cast<const uint4 *>(toff), *s1 = reinterpret_cast<const uint4 *>(qoff);
+                uint4 *d0 = reinterpret_cast<uint4 *>(sT), *d1 = reinterpret_cast<uint4 *>(sQ32);
+                for (uint32_t k = threadIdx.x; k < TILE_WORDS / 4; k += THREADS) { d0[k] = s0[k]; d1[k] = s1[k]; }
+                if (threadIdx.x == 0) { sT[TILE_WORDS] = t0 + nT; sQ32[TILE_WORDS] = q0 + nQ; *s_total = 0ull; }
+            }
+            __syncthreads();
+            unsigned long long cnt = 0;
+            for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS) {
+                const uint32_t nt = sT[w + 1] - sT[w];
+                if (nt) {
+                    uint32_t sum = sQ32[w + 1] - sQ32[w];
+                    if (A.transitions)
+                        for (int j = 0; j < SEED_WEIGHT; j++) { const uint32_t w2 = w ^ (1u << j); sum += sQ32[w2 + 1] - sQ32[w2]; }
+                    cnt += (unsigned long long)nt * sum;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0 && cnt) atomicAdd(s_total, cnt);
+            __syncthreads();
+            const unsigned long long tile_total = *s_total;
+            if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = tile_total;
+            if (!tile_total) return;
+            if (tile_total > HEAVY_HITS || nQ > 0xFFFFu) {
+                if (threadIdx.x == 0) A.q.heavy[atomicAdd(&A.q.ctr->nheavy, 1ull)] = tile;   // at most NTILE entries
+                return;
+            }
+            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] = (qoff_t)(sQ32[k] - q0);   // relative to the tile's first query entry
+            __syncthreads();   // ... before the frames overwrite the staged offsets
+        } else {
+            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] = qoff[k] - q0;
+        }
+        const bool single = nQ <= QSEG;   // the whole query tile in one segment: no clipping of the neighbour ranges
+        const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
+        const uint32_t nchunks = (nT + TCH - 1) / TCH;
+        // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
+        const uint32_t ch_first = (HEAVY ? blockIdx.y * WAVES : 0u) + wv, ch_step = (HEAVY ? gridDim.y : 1u) * WAVES;
+        // my first chunk's frames (one entry per lane): in flight while the first query segment is staged
+        uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = nf0, nf2 = nf0;
+        uint32_t npos = 0;
+        if (ch_first < nchunks) {
+            const uint32_t e = ch_first * TCH + lane;
+            if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+        }
+        const uint32_t qs_first = HEAVY ? blockIdx.z * QSEG : 0u, qs_step = (HEAVY ? gridDim.z : 1u) * QSEG;
+        for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
+            const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
+            __syncthreads();  // every wavefront is through with the previous segment (and sQ is complete)
+            {
+                const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
+                for (uint32_t i = threadIdx.x; i < qn; i += THREADS) {
+                    sQF[i] = s0[i];
+                    sQF[QSEG + i] = s1[i];
+                    sQF[2 * QSEG + i] = s2[i];
+                    sQN[i] = (uint8_t)(A.Q.pos[q0 + qs + i] >> 31);
+                }
+            }
+            __syncthreads();
+            for (uint32_t ch = ch_first; ch < nchunks; ch += ch_step) {
+                const uint32_t e0 = ch * TCH, ne = min(TCH, nT - e0);
+                const uint4 f0 = nf0, f1 = nf1, f2 = nf2;
+                const uint32_t mypos = npos;
+                {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
+                    uint32_t nx = ch + ch_step;
+                    if (nx >= nchunks) nx = (qs + qs_step < nQ) ? ch_first : 0xFFFFFFFFu;
+                    if (nx != 0xFFFFFFFFu && nx != ch) {
+                        const uint32_t e = nx * TCH + lane;
+                        if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+                    }
+                }
+                const bool tvalid = lane < ne;
+                // my entry's in-tile key from its own frame: hi plane, seed window = frame bits 109 .. 127 (hi3 = f2.y)
+                uint32_t w = 0, c = 0, nmask = 0;
+                if (tvalid) {
+                    w = pext12(f2.y >> 13);
+                    const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
+                    if (single) {
+                        for (int j = 0; j < nn; j++) {
+                            const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                            const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                            c += b - a;
+                            nmask |= (b != a ? 1u : 0u) << j;
+                        }
+                    } else {
+                        for (int j = 0; j < nn; j++) {
+                            const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                            const uint32_t a = max((uint32_t)sQ[w2], qs), b = min((uint32_t)sQ[w2 + 1], qe);
+                            if (a < b) { c += b - a; nmask |= 1u << j; }
+                        }
+                    }
+                }
+                // inclusive prefix sum over the lanes: DPP (VALU latency), not six trips through the LDS crossbar
+                uint32_t inc = c;
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), st = inc - c;
+                for (uint32_t rb = 0; rb < tot; rb += DQ) {
+                    if (c && st < rb + DQ && st + c > rb) {
+                        uint32_t acc = st;
+                        for (uint32_t m = nmask; m; m &= m - 1u) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(m);
+                            const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
+                            const uint32_t a = max((uint32_t)sQ[w2], qs), b = min((uint32_t)sQ[w2 + 1], qe);
+                            const uint32_t g0 = max(acc, rb), g1 = min(acc + (b - a), rb + DQ);
+                            for (uint32_t g = g0; g < g1; g++) sD[g - rb] = (lane << 16) | (a + (g - acc) - qs);
+                            acc += b - a;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t n = min(DQ, tot - rb);
+                    for (uint32_t i = 0; i < n; i += 64) {
+                        const bool valid = i + lane < n;
+                        const uint32_t d = valid ? sD[i + lane] : 0u;
+                        const uint32_t owner = d >> 16, qi = d & 0xFFFFu;
+                        // the target frame lives in its owner lane's registers, the query frame in LDS
+                        const uint4 ta = bperm4(owner, f0), tb = bperm4(owner, f1), tc = bperm4(owner, f2);
+                        const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
+                        const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
+                        bool need = false;
+                        if (valid) {
+                            if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
+                            else need = ((tpf >> 31) | sQN[qi]) != 0 ||
+                                        pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
+                            if (A.dbg & 2u) need = false;
+                        }
+                        uint32_t qp = 0;
+                        if (A.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
+                            if (valid) {
+                                qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                                if ((tpf & POS_MASK) == qp) need = false;
+                            }
+                        } else if (need) {
+                            qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                        }
+                        const uint64_t m = __ballot(need);
+                        if (m) {
+                            const uint32_t add = (uint32_t)__popcll(m);
+                            if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
+                            if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
+                            n_walk += add;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
-        __syncthreads();
-        for (uint32_t ch = ch_first; ch < nchunks; ch += ch_step) {
-            const uint32_t e0 = ch * TCH, ne = min(TCH, nT - e0);
-            const uint4 f0 = nf0, f1 = nf1, f2 = nf2;
-            const uint32_t mypos = npos;
-            {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
-                uint32_t nx = ch + ch_step;
-                if (nx >= nchunks) nx = (qs + qs_step < nQ) ? ch_first : 0xFFFFFFFFu;
-                if (nx != 0xFFFFFFFFu && nx != ch) {
-                    const uint32_t e = nx * TCH + lane;
-                    if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
-                }
-            }
-            const bool tvalid = lane < ne;
-            const uint32_t tflag = tvalid ? (mypos >> 31) : 0u;
-            // my entry's in-tile key from its own frame: hi plane, seed window = frame bits 109 .. 127 (hi3 = f2.y)
-            uint32_t w = 0, c = 0, nmask = 0;
-            if (tvalid) {
-                w = pext12(f2.y >> 13);
-                const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
-                if (single) {
-                    for (int j = 0; j < nn; j++) {
-                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                        const uint32_t a = sQ[w2], b = sQ[w2 + 1];
-                        c += b - a;
-                        nmask |= (b != a ? 1u : 0u) << j;
-                    }
-                } else {
-                    for (int j = 0; j < nn; j++) {
-                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                        const uint32_t a = max(sQ[w2], qs), b = min(sQ[w2 + 1], qe);
-                        if (a < b) { c += b - a; nmask |= 1u << j; }
-                    }
-                }
-            }
-            uint32_t inc = c;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t v = __shfl_up(inc, o);
-                if (lane >= (uint32_t)o) inc += v;
-            }
-            const uint32_t tot = __shfl(inc, 63), st = inc - c;
-            for (uint32_t rb = 0; rb < tot; rb += DQ) {
-                if (c && st < rb + DQ && st + c > rb) {
-                    uint32_t acc = st;
-                    for (uint32_t m = nmask; m; m &= m - 1u) {
-                        const uint32_t j = (uint32_t)__builtin_ctz(m);
-                        const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
-                        const uint32_t a = max(sQ[w2], qs), b = min(sQ[w2 + 1], qe);
-                        const uint32_t g0 = max(acc, rb), g1 = min(acc + (b - a), rb + DQ);
-                        for (uint32_t g = g0; g < g1; g++) sD[g - rb] = (lane << 16) | (a + (g - acc) - qs);
-                        acc += b - a;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t n = min(DQ, tot - rb);
-                for (uint32_t i = 0; i < n; i += 64) {
-                    const bool valid = i + lane < n;
-                    const uint32_t d = valid ? sD[i + lane] : 0u;
-                    const uint32_t owner = d >> 16, qi = d & 0xFFFFu;
-                    // the target frame lives in its owner lane's registers, the query frame in LDS
-                    const uint4 ta = bperm4(owner, f0), tb = bperm4(owner, f1), tc = bperm4(owner, f2);
-                    const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
-                    const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
-                    bool need = false;
-                    if (valid) {
-                        if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
-                        else need = ((tpf >> 31) | sQN[qi]) != 0 ||
-                                    pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
-                        if (A.dbg & 2u) need = false;
-                    }
-                    uint32_t qp = 0;
-                    if (A.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
-                        if (valid) {
-                            qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
-                            if ((tpf & POS_MASK) == qp) need = false;
-                        }
-                    } else if (need) {
-                        qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
-                    }
-                    const uint64_t m = __ballot(need);
-                    if (m) {
-                        const uint32_t add = (uint32_t)__popcll(m);
-                        if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
-                        if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
-                        n_walk += add;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            (void)tflag;
+    };
+
+    if (!HEAVY) {
+        do_tile(blockIdx.x);
+    } else {
+        const uint32_t nlist = (uint32_t)min((unsigned long long)NTILE, A.q.ctr->nheavy);
+        for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) {
+            do_tile(A.q.heavy[li]);
+            __syncthreads();   // the next tile's offsets overwrite this one's
         }
     }
     if (n_walk) flush_walk(n_walk);
+    (void)s_slot;
 }
 
 // one workgroup per unit: unit_hits[u] = sum of its tile counts (once per batch)
@@ -364,25 +375,11 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st) {
     hipLaunchKernelGGL(k34_sum_hits, dim3(nunits), dim3(256), 0, st, (const unsigned long long *)q.tile_hits, q.unit_hits);
 }
 
-// The split pass is launched with a fixed grid: HEAVY_MAX listed tiles x HEAVY_SPLIT (2048 workgroups that exit at once
-// when no tile is heavy: a few microseconds per unit)
+// The split pass is launched with a fixed grid: its workgroups loop over the listed tiles, each cut over HEAVY_SPLIT
+// shares of its target chunks x HEAVY_QSPLIT shares of its query segments (4096 workgroups that exit at once when no tile
+// is listed: a few microseconds per unit)
 static const dim3 HEAVY_GRID(HEAVY_MAX, HEAVY_SPLIT, HEAVY_QSPLIT);
-template <int THREADS, uint32_t QSEG>
-static int launch_cfg(const FusedArgs &A, hipStream_t st) {
-    static bool attr_done = false;
-    constexpr size_t smem = FusedCfg<THREADS, QSEG>::SMEM;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<THREADS, QSEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((k34_scan_extend<THREADS, QSEG>), dim3(NTILE), dim3(THREADS), smem, st, A);
-    // the heavy tiles the first pass listed, each cut over HEAVY_SPLIT workgroups (workgroups beyond the list exit at once)
-    FusedArgs H = A;
-    H.heavy_pass = 1;
-    hipLaunchKernelGGL((k34_scan_extend<THREADS, QSEG>), dim3(HEAVY_GRID), dim3(THREADS), smem, st, H);
-    return 0;
-}
+constexpr uint32_t QSEG_FIRST = 1280, QSEG_HEAVY = 1024;
 
 int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
                       hipStream_t st) {
@@ -393,15 +390,20 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
     A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
     A.heavy_pass = 0; A.heavy_base = 0;
     A.dbg = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
-    // workgroup shape: one 1024-thread workgroup per CU with a 2048-entry query segment (most 10 Mbp x 10 Mbp tiles in
-    // two passes), or two 512-thread workgroups per CU with 1024-entry segments (scaffolds up to ~5 Mbp: one pass)
-    static const int cfg = getenv("MIMEO_K34_CFG") ? atoi(getenv("MIMEO_K34_CFG")) : 0;
-    const uint32_t avg = (uint32_t)(((uint64_t)w.qi.n + NTILE - 1) / NTILE);
-    const bool big = cfg ? cfg == 1 : false;  // measured: two 512-thread workgroups per CU win on 10 Mbp tiles too (1.30 vs 1.62 ms per C4 unit)
-    (void)avg;
-    if (cfg == 3) return launch_cfg<768, 2560>(A, st);
-    if (cfg == 4) return launch_cfg<512, 2560>(A, st);
-    return big ? launch_cfg<1024, 2048>(A, st) : launch_cfg<512, 1024>(A, st);
+    constexpr size_t smem_heavy = FusedCfg<512, QSEG_HEAVY, true>::SMEM, smem_first = FusedCfg<512, QSEG_FIRST, false>::SMEM;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_FIRST, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_first));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_HEAVY, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_heavy));
+        attr_done = true;
+    }
+    // measured on a C4 unit (two segments per tile at 1280, three at 1216 and 1024): 1.44 / 1.51 / 1.54 ms for the heavy phase
+    hipLaunchKernelGGL((k34_scan_extend<512, QSEG_FIRST, false>), dim3(NTILE), dim3(512), smem_first, st, A);
+    A.heavy_pass = 1;
+    hipLaunchKernelGGL((k34_scan_extend<512, QSEG_HEAVY, true>), dim3(HEAVY_GRID), dim3(512), smem_heavy, st, A);
+    return 0;
 }
 
 }  // namespace mimeo
