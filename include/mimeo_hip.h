@@ -131,7 +131,7 @@ typedef struct mimeo_stats {
     uint64_t queue_reruns;        /* batches repeated because a queue sized for random sequence overflowed (repeat-rich units) */
     uint64_t walked_hits;         /* seed hits the pre-filter could not dismiss: walked exactly */
     uint64_t followers;           /* hits with an earlier seed hit of their diagonal in reach: resolved after one sort per batch */
-    uint64_t reserved[1];
+    uint64_t super_units;         /* units of super-scaffolds (small scaffolds packed behind spacers: fragmented assemblies); 0 = the call ran one unit per scaffold pair and strand */
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */

@@ -217,6 +217,30 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                   uint64_t nhsps, const mimeo_params *p, mimeo_alignment *d_aln);
 // alignments of all groups packed densely (group g: d_dense[job0 .. job0 + naln)); same stream as gapped_device
 void dense_alignments_device(Group *d_groups, uint32_t ngroups, const mimeo_alignment *d_aln, mimeo_alignment *d_dense);
+// ---- super-scaffolds (pack.hip): small scaffolds concatenated behind spacers of N for K2 / K34 / K4 -------------------
+struct PackMember { uint32_t id, start, len; };   // scaffold number, first base inside the super-scaffold, bases
+struct SuperSide {
+    std::vector<Scaffold> supers;                   // a super of ONE member at offset 0 is the scaffold itself (not owned)
+    std::vector<bool> owned;
+    std::vector<std::vector<PackMember>> members;
+    std::vector<uint32_t> super_of, start_of;       // per scaffold number of the genome (0xFFFFFFFF: takes no part)
+    void release();
+};
+int build_super_side(const mimeo_genome *g, const std::vector<uint32_t> &ids, uint32_t spacer, uint64_t member_max,
+                     uint64_t super_len, SuperSide &out);
+struct RegroupTables {   // device pointers
+    const uint3 *unit_tab;                                // per unit of the batch: target super, query super, minus
+    const uint32_t *t_off, *t_start, *t_len, *t_rank;     // members of target super s: slots t_off[s] .. t_off[s + 1]; rank in the target set
+    const uint32_t *q_off, *q_start, *q_len, *q_rank;
+    const uint32_t *pairidx;                              // [t_rank * nq + q_rank] -> index of the pair in pair_t / pair_q
+    uint32_t nq, pad;
+    const uint32_t *pair_t, *pair_q;                      // scaffold numbers of the pairs
+    const StrandView *t_view, *q_view_fwd, *q_view_rc;    // per scaffold number
+};
+int regroup_hsps_device(mimeo_hsp *d_hsps, uint32_t *d_hunit, uint64_t nh, const RegroupTables &R, uint32_t npairs, DeviceBuf &groups,
+                        uint32_t *ngroups);
+int group_summary_device(const Group *d_groups, uint32_t ngroups, uint64_t out[3]);
+void release_pack_buffers();
 // chain + gapped extension of every group (pipeline.hip)
 int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
                         const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,

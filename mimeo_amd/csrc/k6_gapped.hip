@@ -843,7 +843,7 @@ __global__ __launch_bounds__(ANCHOR_THREADS) void k6_anchor_points(const Group *
                                                                    unsigned long long *__restrict__ packed) {
     const Group &G = groups[blockIdx.x];
     const uint64_t b0 = G.hsp_begin;
-    const uint32_t nw = ANCHOR_SPLIT * (ANCHOR_THREADS / 64), me = blockIdx.y * (ANCHOR_THREADS / 64) + (threadIdx.x >> 6);
+    const uint32_t nw = gridDim.y * (ANCHOR_THREADS / 64), me = blockIdx.y * (ANCHOR_THREADS / 64) + (threadIdx.x >> 6);
     uint32_t item = 0;
     for (uint32_t r = 0; r < G.nchain; r++) {
         const mimeo_hsp h = hs[b0 + order[b0 + r]];
@@ -1260,7 +1260,9 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         HIP_TRY(hipMemsetAsync(g_astate.p, 0, (size_t)nhsps * 2, st));
         if ((rc = g_cnt.reserve(16))) return rc;
         if ((rc = g_ovf_list.reserve((size_t)ngroups * bmax * 2 * sizeof(unsigned int)))) return rc;
-        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups, ANCHOR_SPLIT), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups,
+        // many small groups (scaffold pairs of a packed fragmented assembly): one workgroup each will do
+        const uint32_t asplit = ngroups > 4096 ? 1u : ANCHOR_SPLIT;
+        hipLaunchKernelGGL(k6_anchor_points, dim3(ngroups, asplit), dim3(ANCHOR_THREADS), 0, st, (const Group *)d_groups,
                            d_sorted, d_order, (unsigned long long *)g_packed.p);
         hipLaunchKernelGGL(k6_anchor_final, dim3(ngroups), dim3(256), 0, st, (const Group *)d_groups, d_sorted, d_order,
                            (const unsigned long long *)g_packed.p, (uint2 *)g_anchors.p);

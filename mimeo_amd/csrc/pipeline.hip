@@ -54,9 +54,11 @@ struct IndexCache {
         Key k = key_of(s, minus, as_target, &sv);
         if (!seen.insert(k).second) return;
         owner_of[k] = owner;
-        auto it = owner->kept.find(kept_key(owner, k));
-        if (it != owner->kept.end()) { m.emplace(k, it->second); adopted.insert(k); }
-        else plan.emplace_back(k, sv);
+        if (owner) {
+            auto it = owner->kept.find(kept_key(owner, k));
+            if (it != owner->kept.end()) { m.emplace(k, it->second); adopted.insert(k); return; }
+        }
+        plan.emplace_back(k, sv);
     }
     int build_all() {
         for (auto &job : plan) {
@@ -103,6 +105,7 @@ void release_pipeline_buffers() {
     g_aln.release();
     g_dense.release();
     g_groups.release();
+    release_pack_buffers();
 }
 
 // the extension stage of an arbitrary unit list, HSPs copied to the host per unit (stage entry point
@@ -120,6 +123,198 @@ int ungapped_units(const std::vector<UnitWork> &work, const mimeo_params *p, std
     HIP_TRY(hipMemcpy(u.data(), g_ext.hsp_unit.p, nh * 4, hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < nh; i++) (*per_unit)[u[i]].push_back(h[i]);
     return 0;
+}
+
+// ---- fragmented assemblies: the extension stage on super-scaffolds (pack.hip) ------------------------------------------
+// Taken when the pair list is a full cross product T x Q (what every mimeo workflow asks for) with at least
+// MIMEO_PACK_MIN (16) scaffolds of at most MIMEO_PACK_MEMBER (2 Mbp) bases on one side; MIMEO_PACK=0 switches it off.
+// *used = false: the caller runs the unit-per-pair path.
+template <typename T>
+static int upload(DeviceBuf &b, const std::vector<T> &v) {
+    int rc = b.reserve((v.size() ? v.size() : 1) * sizeof(T));
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream()));
+    return 0;
+}
+
+static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint32_t *pair_t, const uint32_t *pair_q, uint64_t npairs,
+                      const mimeo_params *p, std::vector<std::vector<mimeo_alignment>> &per_pair, ExtStats &est, float &ms_chain,
+                      float &ms_gapped, float &ms_index, bool *used) {
+    *used = false;
+    if (getenv("MIMEO_PACK") && !atoi(getenv("MIMEO_PACK"))) return 0;
+    if (npairs == 0 || npairs >= (1ull << 30)) return 0;
+    const uint64_t member_max = getenv("MIMEO_PACK_MEMBER") ? (uint64_t)atol(getenv("MIMEO_PACK_MEMBER")) : (2ull << 20);
+    const uint64_t super_len = getenv("MIMEO_PACK_SUPER") ? (uint64_t)atol(getenv("MIMEO_PACK_SUPER")) : (8ull << 20);
+    const size_t pack_min = getenv("MIMEO_PACK_MIN") ? (size_t)atol(getenv("MIMEO_PACK_MIN")) : 16;
+    std::vector<uint32_t> tset(pair_t, pair_t + npairs), qset(pair_q, pair_q + npairs);
+    std::sort(tset.begin(), tset.end()); tset.erase(std::unique(tset.begin(), tset.end()), tset.end());
+    std::sort(qset.begin(), qset.end()); qset.erase(std::unique(qset.begin(), qset.end()), qset.end());
+    size_t small_t = 0, small_q = 0;
+    for (uint32_t t : tset) small_t += A->scaf[t].len <= member_max;
+    for (uint32_t q : qset) small_q += QG->scaf[q].len <= member_max;
+    if (std::max(small_t, small_q) < pack_min) return 0;
+    const bool self = (A == QG);
+    if (self && tset != qset) return 0;   // the main diagonals need target and query of a scaffold in ONE super-scaffold
+    // the pair list must be the full cross product (duplicates are answered from their first occurrence)
+    std::vector<uint32_t> trank(A->scaf.size(), 0xFFFFFFFFu), qrank(QG->scaf.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < tset.size(); i++) trank[tset[i]] = (uint32_t)i;
+    for (size_t i = 0; i < qset.size(); i++) qrank[qset[i]] = (uint32_t)i;
+    const size_t nq = qset.size();
+    std::vector<uint32_t> pairidx(tset.size() * nq, 0xFFFFFFFFu);
+    std::vector<std::pair<uint64_t, uint64_t>> dups;   // (duplicate, first occurrence)
+    size_t distinct = 0;
+    for (uint64_t k = 0; k < npairs; k++) {
+        uint32_t &slot = pairidx[(size_t)trank[pair_t[k]] * nq + qrank[pair_q[k]]];
+        if (slot == 0xFFFFFFFFu) { slot = (uint32_t)k; distinct++; } else dups.emplace_back(k, slot);
+    }
+    if (distinct != pairidx.size()) return 0;
+
+    const uint32_t spacer = (uint32_t)std::max(64, p->xdrop / 100 + 32);
+    SuperSide side_t, side_q;
+    int rc = build_super_side(A, tset, spacer, member_max, super_len, side_t);
+    if (!rc && !self) rc = build_super_side(QG, qset, spacer, member_max, super_len, side_q);
+    if (rc) { side_t.release(); side_q.release(); return rc; }
+    SuperSide &ST = side_t, &SQ = self ? side_t : side_q;
+    struct Cleanup { SuperSide &a, &b; ~Cleanup() { a.release(); b.release(); } } cleanup{side_t, side_q};
+    // seed indexes of the supers must fit (no index blocks on this path: the unit-per-pair path has them)
+    {
+        uint64_t need = 0;
+        const int qroles = ((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH) ? 2 : 1;
+        for (auto &s : ST.supers) need += seed_index_bytes(s.len);
+        for (auto &s : SQ.supers) need += seed_index_bytes(s.len) * qroles;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = (uint64_t)(0.6 * (double)free_b);
+        if (getenv("MIMEO_INDEX_BUDGET_MB")) budget = (uint64_t)atol(getenv("MIMEO_INDEX_BUDGET_MB")) << 20;
+        if (need > budget) return 0;
+    }
+    *used = true;
+    hipStream_t st = stream();
+    // ---- device tables
+    static DeviceBuf d_toff, d_tstart, d_tlen, d_trank, d_qoff, d_qstart, d_qlen, d_qrank, d_pairidx, d_pt, d_pq, d_tview, d_qvf, d_qvr, d_utab;
+    auto member_tables = [&](const SuperSide &S, const std::vector<uint32_t> &rank, std::vector<uint32_t> &off, std::vector<uint32_t> &start,
+                             std::vector<uint32_t> &len, std::vector<uint32_t> &rk) {
+        off.assign(1, 0u);
+        for (auto &mem : S.members) {
+            for (const PackMember &m : mem) { start.push_back(m.start); len.push_back(m.len); rk.push_back(rank[m.id]); }
+            off.push_back((uint32_t)start.size());
+        }
+    };
+    std::vector<uint32_t> h_toff, h_tstart, h_tlen, h_trank, h_qoff, h_qstart, h_qlen, h_qrank;
+    member_tables(ST, trank, h_toff, h_tstart, h_tlen, h_trank);
+    member_tables(SQ, qrank, h_qoff, h_qstart, h_qlen, h_qrank);
+    std::vector<StrandView> h_tview(A->scaf.size()), h_qvf(QG->scaf.size()), h_qvr(QG->scaf.size());
+    memset(h_tview.data(), 0, h_tview.size() * sizeof(StrandView));
+    memset(h_qvf.data(), 0, h_qvf.size() * sizeof(StrandView));
+    memset(h_qvr.data(), 0, h_qvr.size() * sizeof(StrandView));
+    for (uint32_t t : tset) { IndexCache::key_of(A->scaf[t], 0, true, &h_tview[t]); }
+    for (uint32_t q : qset) { IndexCache::key_of(QG->scaf[q], 0, false, &h_qvf[q]); IndexCache::key_of(QG->scaf[q], 1, false, &h_qvr[q]); }
+    std::vector<uint32_t> h_pt(pair_t, pair_t + npairs), h_pq(pair_q, pair_q + npairs);
+    if ((rc = upload(d_toff, h_toff)) || (rc = upload(d_tstart, h_tstart)) || (rc = upload(d_tlen, h_tlen)) || (rc = upload(d_trank, h_trank)) ||
+        (rc = upload(d_qoff, h_qoff)) || (rc = upload(d_qstart, h_qstart)) || (rc = upload(d_qlen, h_qlen)) || (rc = upload(d_qrank, h_qrank)) ||
+        (rc = upload(d_pairidx, pairidx)) || (rc = upload(d_pt, h_pt)) || (rc = upload(d_pq, h_pq)) || (rc = upload(d_tview, h_tview)) ||
+        (rc = upload(d_qvf, h_qvf)) || (rc = upload(d_qvr, h_qvr)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of use only at the end of the call; be plain about it
+    RegroupTables R;
+    R.t_off = (const uint32_t *)d_toff.p; R.t_start = (const uint32_t *)d_tstart.p; R.t_len = (const uint32_t *)d_tlen.p; R.t_rank = (const uint32_t *)d_trank.p;
+    R.q_off = (const uint32_t *)d_qoff.p; R.q_start = (const uint32_t *)d_qstart.p; R.q_len = (const uint32_t *)d_qlen.p; R.q_rank = (const uint32_t *)d_qrank.p;
+    R.pairidx = (const uint32_t *)d_pairidx.p; R.nq = (uint32_t)nq; R.pad = 0;
+    R.pair_t = (const uint32_t *)d_pt.p; R.pair_q = (const uint32_t *)d_pq.p;
+    R.t_view = (const StrandView *)d_tview.p; R.q_view_fwd = (const StrandView *)d_qvf.p; R.q_view_rc = (const StrandView *)d_qvr.p;
+
+    // ---- units: (target super, query super, strand), target-major
+    struct SUnit { uint32_t ts, qs, minus; };
+    std::vector<SUnit> units;
+    uint64_t max_t = 1, max_q = 1;
+    for (uint32_t ts = 0; ts < ST.supers.size(); ts++)
+        for (uint32_t qs = 0; qs < SQ.supers.size(); qs++)
+            for (uint32_t minus = 0; minus < 2; minus++)
+                if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS)) units.push_back(SUnit{ts, qs, minus});
+    for (auto &s : ST.supers) max_t = std::max<uint64_t>(max_t, s.len);
+    for (auto &s : SQ.supers) max_q = std::max<uint64_t>(max_q, s.len);
+    IndexCache cache;
+    {
+        std::set<IndexCache::Key> seen;
+        for (const SUnit &u : units) {
+            cache.want(nullptr, ST.supers[u.ts], 0, true, seen);
+            cache.want(nullptr, SQ.supers[u.qs], (int)u.minus, false, seen);
+        }
+    }
+    rc = cache.build_all();
+    size_t max_units = std::min<size_t>(8192, ext_batch_max_units(max_t, max_q));
+    if (getenv("MIMEO_BATCH_UNITS")) max_units = std::max<size_t>(1, std::min<size_t>(max_units, (size_t)atol(getenv("MIMEO_BATCH_UNITS"))));
+    const double max_hits = getenv("MIMEO_BATCH_HITS") ? atof(getenv("MIMEO_BATCH_HITS")) : 2.5e10;
+    const uint64_t max_groups = 1ull << 22;   // K5 names a group in 23 bits
+    for (size_t b0 = 0; b0 < units.size() && !rc;) {
+        std::vector<UnitWork> work;
+        std::vector<uint3> utab;
+        double hits = 0;
+        uint64_t tmembers = 0;
+        uint32_t last_ts = 0xFFFFFFFFu;
+        size_t b1 = b0;
+        for (; b1 < units.size() && work.size() < max_units; b1++) {
+            const SUnit &u = units[b1];
+            UnitWork w;
+            memset(&w, 0, sizeof w);
+            if ((rc = cache.get(ST.supers[u.ts], 0, true, &w.ti, &w.d.T)) || (rc = cache.get(SQ.supers[u.qs], (int)u.minus, false, &w.qi, &w.d.Q))) break;
+            const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
+            const uint64_t tm_new = tmembers + (u.ts != last_ts ? ST.members[u.ts].size() : 0);
+            if (!work.empty() && (hits + e > max_hits || tm_new * nq * 2 > max_groups)) break;
+            hits += e; tmembers = tm_new; last_ts = u.ts;
+            w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1u : 0u;
+            work.push_back(w);
+            utab.push_back(make_uint3(u.ts, u.qs, u.minus));
+        }
+        if (rc) break;
+        uint64_t nh = 0;
+        if ((rc = g_ext.run(work, p, &nh, &est))) break;
+        g_stats.super_units += work.size();
+        g_stats.hsps += nh;
+        for (size_t i = b0; i < b1; i++) g_stats.query_bases_scanned += SQ.supers[units[i].qs].len;
+        g_stats.batches++;
+        if (nh) {
+            if ((rc = upload(d_utab, utab))) break;
+            R.unit_tab = (const uint3 *)d_utab.p;
+            uint32_t ngroups = 0;
+            if ((rc = regroup_hsps_device((mimeo_hsp *)g_ext.hsps.p, (uint32_t *)g_ext.hsp_unit.p, nh, R, (uint32_t)npairs, g_groups, &ngroups))) break;
+            if (ngroups >= (1u << 23)) { set_error("more than 2^23 scaffold pairs with HSPs in one batch"); rc = MIMEO_ERR_LIMIT; break; }
+            if (!ngroups) { b0 = b1; continue; }
+            if ((rc = g_aln.reserve(nh * sizeof(mimeo_alignment))) || (rc = g_dense.reserve(nh * sizeof(mimeo_alignment)))) break;
+            if ((rc = chain_gapped_device((Group *)g_groups.p, ngroups, (const mimeo_hsp *)g_ext.hsps.p, (const uint32_t *)g_ext.hsp_unit.p, nh, p,
+                                          g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain, &ms_gapped)))
+                break;
+            dense_alignments_device((Group *)g_groups.p, ngroups, (const mimeo_alignment *)g_aln.p, (mimeo_alignment *)g_dense.p);
+            uint64_t sum[3] = {0, 0, 0};
+            if ((rc = group_summary_device((const Group *)g_groups.p, ngroups, sum))) break;
+            Group last;
+            HIP_TRY(hipMemcpy(&last, (const Group *)g_groups.p + (ngroups - 1), sizeof(Group), hipMemcpyDeviceToHost));
+            if (sum[1]) {
+                Group bad;
+                HIP_TRY(hipMemcpy(&bad, (const Group *)g_groups.p + (sum[2] - 1), sizeof(Group), hipMemcpyDeviceToHost));
+                char msg[256];
+                snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns, or "
+                         "score beyond int32: not supported", bad.tid, bad.qid, bad.minus ? '-' : '+');
+                set_error(msg);
+                rc = MIMEO_ERR_LIMIT;
+                break;
+            }
+            g_stats.chained_hsps += sum[0];
+            const uint64_t naln_total = (uint64_t)last.job0 + last.naln;
+            std::vector<mimeo_alignment> host_aln(naln_total);
+            if (naln_total) HIP_TRY(hipMemcpy(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost));
+            // dense order = (pair, strand) order: a pair's plus-strand alignments come before its minus-strand ones, as on the other path
+            for (const mimeo_alignment &a : host_aln) per_pair[pairidx[(size_t)trank[a.tid] * nq + qrank[a.qid]]].push_back(a);
+        }
+        b0 = b1;
+    }
+    cache.clear();
+    ms_index += cache.ms;
+    g_stats.index_blocks++;
+    g_stats.pair_strands += distinct * (((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH) ? 2 : 1);
+    if (!rc)
+        for (auto &d : dups) per_pair[d.first] = per_pair[d.second];
+    return rc;
 }
 
 int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
@@ -143,6 +338,13 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))
                 units.push_back(Unit{ord[k], pair_t[ord[k]], pair_q[ord[k]], minus});
     std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
+    float ms_chain = 0, ms_gapped = 0, ms_index = 0;
+    ExtStats est;
+    int rc = 0;
+    bool packed = false;
+    HIP_TRY(hipStreamSynchronize(stream()));
+    if ((rc = run_packed(A, QG, pair_t, pair_q, npairs, p, per_pair, est, ms_chain, ms_gapped, ms_index, &packed))) return rc;
+    if (!packed) {
     // Seed indexes cost 64 MiB + 52 bytes per base and strand, so a large or fragmented genome cannot keep them all
     // (a 1 Gbp genome, both strands: 117 GB; 2000 small scaffolds x 2 strands: 256 GB of offset arrays).  When the
     // indexes a call needs exceed the budget (60 % of the free device memory; MIMEO_INDEX_BUDGET_MB for tests) the
@@ -193,9 +395,6 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     size_t max_units = std::min<size_t>(MAX_GROUPS, ext_batch_max_units(max_t, max_q));
     if (getenv("MIMEO_BATCH_UNITS")) max_units = std::max<size_t>(1, std::min<size_t>(max_units, (size_t)atol(getenv("MIMEO_BATCH_UNITS"))));
     const double max_hits = getenv("MIMEO_BATCH_HITS") ? atof(getenv("MIMEO_BATCH_HITS")) : 2.5e10;
-    float ms_chain = 0, ms_gapped = 0, ms_index = 0;
-    ExtStats est;
-    int rc = 0;
     hipStream_t st = stream();
     HIP_TRY(hipStreamSynchronize(st));
     size_t blk_begin = 0;
@@ -301,6 +500,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         ms_index += cache.ms;
         g_stats.index_blocks++;
     }
+    }   // !packed
     if (rc) return rc;
     uint64_t total = 0;
     for (auto &v : per_pair) total += v.size();

@@ -1,0 +1,121 @@
+"""Super-scaffolds for fragmented assemblies (pack.hip): the per-pair loop of the reference (src/mimeo/wrappers.py:1015-1059)
+runs lastz once per ordered scaffold pair; this library runs the seed index and the gap-free stage on small scaffolds
+concatenated behind spacers of N and hands every HSP back to its scaffold pair.  The alignments must be byte for byte
+those of the unit-per-pair path, and those of the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from mimeo_amd.synth import synth_genome, make_families
+
+pytestmark = pytest.mark.gpu
+
+PACK_KNOBS = ('MIMEO_PACK', 'MIMEO_PACK_MIN', 'MIMEO_PACK_SUPER', 'MIMEO_PACK_MEMBER', 'MIMEO_BATCH_UNITS')
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mimeo_amd import engine
+    engine.init(0)
+    return engine
+
+
+def _clear(monkeypatch):
+    for k in PACK_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+
+
+def _digest(a):
+    return a.size, hashlib.md5(a.tobytes()).hexdigest()
+
+
+def _fragmented(seed, nscaf, total, **kw):
+    names, seqs = synth_genome(seed, total, nscaf, repeat_frac=0.15, families=8, cons_len=(200, 1500), max_div=0.12, **kw)
+    rng = np.random.default_rng(seed)
+    # unequal lengths (members must not sit on a regular grid), N runs, a soft-masked stretch, one scaffold too short to seed
+    for i in range(len(seqs)):
+        seqs[i] = seqs[i][:len(seqs[i]) - int(rng.integers(0, len(seqs[i]) // 3))].copy()
+    seqs[1][500:530] = ord('N')
+    seqs[3][-40:] = ord('N')
+    seqs[4][0:25] = ord('N')
+    seqs[2][2000:2600] = np.frombuffer(bytes(seqs[2][2000:2600]).lower(), dtype=np.uint8)
+    seqs[5] = seqs[5][:12].copy()
+    return names, seqs
+
+
+def test_packed_self_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
+    names, seqs = _fragmented(5, 24, 24 * 30_000)
+    g = eng.Genome(names, seqs)
+    pairs = [(t, q) for t in range(24) for q in range(24)]
+    _clear(monkeypatch)
+    monkeypatch.setenv('MIMEO_PACK', '0')
+    ref = eng.align_pairs(g, None, pairs)
+    st0 = eng.stats()
+    assert st0['super_units'] == 0 and st0['pair_strands'] == 2 * 24 * 24
+    outs = {}
+    for tag, env in (('one_super', {}), ('three_supers', {'MIMEO_PACK_SUPER': '250000'}), ('supers_of_two', {'MIMEO_PACK_SUPER': '50000'}),
+                     ('big_ones_alone', {'MIMEO_PACK_MEMBER': '24000', 'MIMEO_PACK_MIN': '2'}), ('one_unit_batches', {'MIMEO_BATCH_UNITS': '1', 'MIMEO_PACK_SUPER': '250000'})):
+        _clear(monkeypatch)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = eng.align_pairs(g, None, pairs)
+        st = eng.stats()
+        assert st['super_units'] > 0, tag
+        assert st['pair_strands'] == st0['pair_strands'] and st['hsps'] == st0['hsps'] and st['chained_hsps'] == st0['chained_hsps'], (tag, st, st0)
+        outs[tag] = _digest(a)
+        if tag == 'one_super':
+            assert st['super_units'] == 2
+    _clear(monkeypatch)
+    assert ref.size > 50
+    assert set(outs.values()) == {_digest(ref)}, (outs, _digest(ref))
+    g.close()
+
+
+def test_packed_interspecies_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
+    rng = np.random.Generator(np.random.PCG64(11))
+    fams = make_families(rng, 6, (200, 1200))
+    na, sa = synth_genome(21, 18 * 25_000, 18, repeat_frac=0.15, shared_families=fams, max_div=0.1, prefix='A')
+    nb, sb = synth_genome(22, 5 * 40_000, 5, repeat_frac=0.15, shared_families=fams, max_div=0.1, prefix='B')
+    A, B = eng.Genome(na, sa), eng.Genome(nb, sb)
+    pairs = [(t, q) for t in range(18) for q in range(5)]
+    _clear(monkeypatch)
+    monkeypatch.setenv('MIMEO_PACK', '0')
+    ref = eng.align_pairs(A, B, pairs)
+    _clear(monkeypatch)
+    a = eng.align_pairs(A, B, pairs)     # 18 small targets: packed by default; the five queries ride along in one super
+    st = eng.stats()
+    assert st['super_units'] == 2
+    assert ref.size > 20 and _digest(a) == _digest(ref)
+    # a pair list that is not a full cross product, and one with a duplicate: the first is left to the other path, the second answered twice
+    a2 = eng.align_pairs(A, B, pairs[:-1])
+    assert eng.stats()['super_units'] == 0
+    r2 = ref[~((ref['tid'] == 17) & (ref['qid'] == 4))]
+    assert _digest(a2) == _digest(r2)
+    a3 = eng.align_pairs(A, B, pairs + [pairs[3]])
+    assert eng.stats()['super_units'] == 2
+    dup = ref[(ref['tid'] == pairs[3][0]) & (ref['qid'] == pairs[3][1])]
+    assert a3.size == ref.size + dup.size and _digest(a3[:ref.size]) == _digest(ref) and _digest(a3[ref.size:]) == _digest(dup)
+    A.close(); B.close()
+    _clear(monkeypatch)
+
+
+def test_packed_alignments_match_the_oracle(eng, monkeypatch):
+    from oracle import oracle as O
+    names, seqs = _fragmented(9, 16, 16 * 12_000)
+    g = eng.Genome(names, seqs)
+    pairs = [(t, q) for t in range(16) for q in range(16)]
+    _clear(monkeypatch)
+    got = eng.align_pairs(g, None, pairs)
+    assert eng.stats()['super_units'] == 2
+    exp_all = []
+    for t, q in pairs:
+        e = O.align_pair(seqs[t].tobytes(), seqs[q].tobytes())
+        e['tid'], e['qid'] = t, q
+        exp_all.append(e)
+    exp = np.concatenate(exp_all)
+    cols = ['tid', 'qid', 'tstart', 'tend', 'qstart', 'qend', 'score', 'id_n', 'id_d', 'qstrand']
+    assert exp.size > 30 and got.size == exp.size
+    bad = np.flatnonzero(got[cols] != exp[cols])
+    assert bad.size == 0, (got[cols][bad[:5]], exp[cols][bad[:5]])
+    g.close()
