@@ -169,11 +169,12 @@ def test_long_extension_beyond_packed_counts(eng):
     g.close()
 
 
-def test_chain_with_tens_of_thousands_of_hsps(eng):
+def test_chain_with_tens_of_thousands_of_hsps(eng, monkeypatch):
     """K5 at a size where its structure matters: ~7e4 HSPs in ONE unit (a low hspthresh on an 800 kbp pair makes
-    nearly every strong seed hit an HSP).  The chained subset — the alignments with gapped extension off — must equal
-    the oracle's O(n^2) chain, and the anchor order (one stable device-wide sort by group, chained, score) must be
-    the oracle's: score descending, then (tstart, qstart, length)."""
+    nearly every strong seed hit an HSP): the two-level kernel for large groups (k5_chain_big: blocks of 2048 HSPs).
+    The chained subset — the alignments with gapped extension off — must equal the oracle's O(n^2) chain, and the
+    anchor order (one stable device-wide sort by group, chained, score) must be the oracle's: score descending, then
+    (tstart, qstart, length).  The one-level kernel (MIMEO_K5_NO_BIG) must give the same."""
     from oracle import oracle as O
     names, seqs = synth_genome(66, 1_600_000, 2, repeat_frac=0.1, families=3, cons_len=(300, 3000), max_div=0.1)
     g = eng.Genome(names, seqs)
@@ -188,4 +189,8 @@ def test_chain_with_tens_of_thousands_of_hsps(eng):
     e = exp[order]
     assert np.array_equal(got['tstart'], e['tstart']) and np.array_equal(got['qstart'], e['qstart'])
     assert np.array_equal(got['tend'] - got['tstart'], e['length']) and np.array_equal(got['score'], e['score'])
+    monkeypatch.setenv('MIMEO_K5_NO_BIG', '1')
+    one_level = eng.align_pair(g, 0, g, 1, eng.default_params(gapped=0, strand=1, hspthresh=1150, entropy=0))
+    monkeypatch.delenv('MIMEO_K5_NO_BIG')
+    assert one_level.tobytes() == got.tobytes()
     g.close()
