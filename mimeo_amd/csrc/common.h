@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/mimeo_hip.h"
+#include "host_plan.h"
 
 namespace mimeo {
 
@@ -218,7 +219,7 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
 // alignments of all groups packed densely (group g: d_dense[job0 .. job0 + naln)); same stream as gapped_device
 void dense_alignments_device(Group *d_groups, uint32_t ngroups, const mimeo_alignment *d_aln, mimeo_alignment *d_dense);
 // ---- super-scaffolds (pack.hip): small scaffolds concatenated behind spacers of N for K2 / K34 / K4 -------------------
-struct PackMember { uint32_t id, start, len; };   // scaffold number, first base inside the super-scaffold, bases
+typedef host_plan::Member PackMember;   // scaffold number, first base inside the super-scaffold, bases (host_plan.h)
 struct SuperSide {
     std::vector<Scaffold> supers;                   // a super of ONE member at offset 0 is the scaffold itself (not owned)
     std::vector<bool> owned;

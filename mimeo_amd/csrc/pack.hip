@@ -89,23 +89,9 @@ int build_super_side(const mimeo_genome *g, const std::vector<uint32_t> &ids, ui
     out.release();
     out.super_of.assign(g->scaf.size(), 0xFFFFFFFFu);
     out.start_of.assign(g->scaf.size(), 0u);
-    // plan
-    std::vector<std::vector<PackMember>> plan;
-    std::vector<PackMember> cur;
-    uint64_t cur_end = 0;
-    auto close = [&]() { if (!cur.empty()) { plan.push_back(cur); cur.clear(); } cur_end = 0; };
-    for (uint32_t id : ids) {
-        const uint64_t len = g->scaf[id].len;
-        if (len > member_max || len == 0) {
-            plan.push_back(std::vector<PackMember>{PackMember{id, 0u, (uint32_t)len}});   // alone (kept in scaffold order among the supers)
-            continue;
-        }
-        uint64_t start = cur.empty() ? 0 : ((cur_end + spacer + 31) / 32) * 32;
-        if (!cur.empty() && start + len > super_len) { close(); start = 0; }
-        cur.push_back(PackMember{id, (uint32_t)start, (uint32_t)len});
-        cur_end = start + len;
-    }
-    close();
+    std::vector<uint64_t> len_of(g->scaf.size());
+    for (size_t i = 0; i < g->scaf.size(); i++) len_of[i] = g->scaf[i].len;
+    const std::vector<std::vector<PackMember>> plan = host_plan::plan_supers(len_of, ids, spacer, member_max, super_len);
     out.supers.resize(plan.size());
     out.owned.assign(plan.size(), false);
     out.members = plan;

@@ -146,29 +146,17 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     const uint64_t member_max = getenv("MIMEO_PACK_MEMBER") ? (uint64_t)atol(getenv("MIMEO_PACK_MEMBER")) : (2ull << 20);
     const uint64_t super_len = getenv("MIMEO_PACK_SUPER") ? (uint64_t)atol(getenv("MIMEO_PACK_SUPER")) : (8ull << 20);
     const size_t pack_min = getenv("MIMEO_PACK_MIN") ? (size_t)atol(getenv("MIMEO_PACK_MIN")) : 16;
-    std::vector<uint32_t> tset(pair_t, pair_t + npairs), qset(pair_q, pair_q + npairs);
-    std::sort(tset.begin(), tset.end()); tset.erase(std::unique(tset.begin(), tset.end()), tset.end());
-    std::sort(qset.begin(), qset.end()); qset.erase(std::unique(qset.begin(), qset.end()), qset.end());
+    host_plan::CrossProduct cp = host_plan::cross_product(pair_t, pair_q, npairs, A->scaf.size(), QG->scaf.size());
+    const std::vector<uint32_t> &tset = cp.tset, &qset = cp.qset, &trank = cp.trank, &qrank = cp.qrank, &pairidx = cp.pairidx;
+    const std::vector<std::pair<uint64_t, uint64_t>> &dups = cp.dups;   // (duplicate, first occurrence): answered from the first
+    const size_t nq = qset.size(), distinct = cp.distinct;
+    if (!cp.full) return 0;   // not the full cross product T x Q
     size_t small_t = 0, small_q = 0;
     for (uint32_t t : tset) small_t += A->scaf[t].len <= member_max;
     for (uint32_t q : qset) small_q += QG->scaf[q].len <= member_max;
     if (std::max(small_t, small_q) < pack_min) return 0;
     const bool self = (A == QG);
     if (self && tset != qset) return 0;   // the main diagonals need target and query of a scaffold in ONE super-scaffold
-    // the pair list must be the full cross product (duplicates are answered from their first occurrence)
-    std::vector<uint32_t> trank(A->scaf.size(), 0xFFFFFFFFu), qrank(QG->scaf.size(), 0xFFFFFFFFu);
-    for (size_t i = 0; i < tset.size(); i++) trank[tset[i]] = (uint32_t)i;
-    for (size_t i = 0; i < qset.size(); i++) qrank[qset[i]] = (uint32_t)i;
-    const size_t nq = qset.size();
-    std::vector<uint32_t> pairidx(tset.size() * nq, 0xFFFFFFFFu);
-    std::vector<std::pair<uint64_t, uint64_t>> dups;   // (duplicate, first occurrence)
-    size_t distinct = 0;
-    for (uint64_t k = 0; k < npairs; k++) {
-        uint32_t &slot = pairidx[(size_t)trank[pair_t[k]] * nq + qrank[pair_q[k]]];
-        if (slot == 0xFFFFFFFFu) { slot = (uint32_t)k; distinct++; } else dups.emplace_back(k, slot);
-    }
-    if (distinct != pairidx.size()) return 0;
-
     const uint32_t spacer = (uint32_t)std::max(64, p->xdrop / 100 + 32);
     SuperSide side_t, side_q;
     int rc = build_super_side(A, tset, spacer, member_max, super_len, side_t);
