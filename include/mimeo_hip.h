@@ -253,6 +253,18 @@ int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t
                             mimeo_interval **out, uint64_t *nout);
 
 /*
+ * bedtools genomecov -bg alone (wrappers.py:1131-1145): the maximal runs of equal depth > 0 of the intervals, in
+ * (chrom, start) order — what `bedtools genomecov -bg -i sorted.bed -g lens` prints, as records.  Serves
+ * scripts/bedtools, the drop-in for the reference's --bedtools option; the library's own workflows
+ * use mimeo_coverage_collapse, which never materialises the runs.
+ */
+typedef struct mimeo_depth_run {
+    uint32_t chrom, start, end, depth;
+} mimeo_depth_run;
+int mimeo_coverage_bedgraph(const mimeo_interval *iv, uint64_t n, const uint32_t *chrom_len, uint32_t nchrom,
+                            mimeo_depth_run **out, uint64_t *nout);
+
+/*
  * Tandem-repeat content of genome slices: the role of `trf F 2 7 7 80 10 50 50 -m -h -ngs` in
  * wrappers.py:120-262 trfFilter (flags run_map.py:145-178).  masked[k] = number of bases of
  * iv[k] = [start, end) on scaffold `chrom` of A that the tandem scorer (K8, DESIGN.md "Tandem

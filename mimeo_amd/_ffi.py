@@ -17,7 +17,7 @@ SYMBOLS = [
     'mimeo_get_stats', 'mimeo_free', 'mimeo_genome_create', 'mimeo_genome_destroy', 'mimeo_genome_nscaf',
     'mimeo_genome_length', 'mimeo_seed_hits', 'mimeo_ungapped_hsps', 'mimeo_align_pair', 'mimeo_align_pairs',
     'mimeo_coverage_collapse', 'mimeo_tandem_masked', 'mimeo_genome_load_fasta', 'mimeo_genome_name',
-    'mimeo_genome_keep_indexes', 'mimeo_genome_drop_indexes', 'mimeo_genome_build_indexes',
+    'mimeo_genome_keep_indexes', 'mimeo_genome_drop_indexes', 'mimeo_genome_build_indexes', 'mimeo_coverage_bedgraph',
 ]
 
 
@@ -44,6 +44,7 @@ ALIGNMENT = np.dtype([('tid', '<u4'), ('qid', '<u4'), ('tstart', '<u4'), ('tend'
                       ('qend', '<u4'), ('score', '<i8'), ('id_n', '<u4'), ('id_d', '<u4'), ('qstrand', '<u4'),
                       ('reserved', '<u4')])
 INTERVAL = np.dtype([('chrom', '<u4'), ('start', '<u4'), ('end', '<u4')])
+DEPTH_RUN = np.dtype([('chrom', '<u4'), ('start', '<u4'), ('end', '<u4'), ('depth', '<u4')])
 
 _lib = None
 
@@ -84,6 +85,8 @@ def load():
         lib.mimeo_align_pairs.argtypes = [vp, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]
     if hasattr(lib, 'mimeo_coverage_collapse'):
         lib.mimeo_coverage_collapse.argtypes = [vp, u64, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)]
+    if hasattr(lib, 'mimeo_coverage_bedgraph'):
+        lib.mimeo_coverage_bedgraph.argtypes = [vp, u64, vp, u32, C.POINTER(vp), C.POINTER(u64)]
     if hasattr(lib, 'mimeo_tandem_masked'):
         lib.mimeo_tandem_masked.argtypes = [vp, vp, u64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     if lib.mimeo_abi_version() != ABI_VERSION:

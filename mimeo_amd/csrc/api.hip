@@ -341,6 +341,21 @@ int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t
     return MIMEO_OK;
 }
 
+int mimeo_coverage_bedgraph(const mimeo_interval *iv, uint64_t n, const uint32_t *chrom_len, uint32_t nchrom, mimeo_depth_run **out,
+                            uint64_t *nout) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!out || !nout || (n && !iv) || (nchrom && !chrom_len)) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    std::vector<mimeo_depth_run> res;
+    if ((rc = coverage_bedgraph_device(iv, n, chrom_len, nchrom, res))) return rc;
+    mimeo_depth_run *r = (mimeo_depth_run *)malloc((res.size() ? res.size() : 1) * sizeof(mimeo_depth_run));
+    if (!r) { set_error("host allocation failed"); return MIMEO_ERR_NOMEM; }
+    if (!res.empty()) memcpy(r, res.data(), res.size() * sizeof(mimeo_depth_run));
+    *out = r;
+    *nout = res.size();
+    return MIMEO_OK;
+}
+
 int mimeo_tandem_masked(const mimeo_genome *A, const mimeo_interval *iv, uint64_t n, int32_t match, int32_t mismatch,
                         int32_t delta, int32_t minscore, int32_t maxperiod, uint32_t *masked) {
     int rc = need_init();

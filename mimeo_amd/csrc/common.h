@@ -247,6 +247,9 @@ int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hs
                         const mimeo_params *p, DeviceBuf &scratch, mimeo_alignment *d_aln, float *ms_chain,
                         float *ms_gapped);
 
+// K7: depth runs (bedtools genomecov -bg); host in, host out (in chrom, start order)
+int coverage_bedgraph_device(const mimeo_interval *h_iv, uint64_t n, const uint32_t *h_chrom_len, uint32_t nchrom,
+                             std::vector<mimeo_depth_run> &out);
 // K7: coverage collapse (k7_collapse.hip); host in, host out (sorted by chrom, start)
 int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint32_t *h_chrom_len, uint32_t nchrom,
                              uint32_t min_cov, uint32_t min_len, std::vector<mimeo_interval> &out, float *ms);

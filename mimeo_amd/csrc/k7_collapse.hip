@@ -148,4 +148,81 @@ int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint3
     return 0;
 }
 
+
+// ---- bedtools genomecov -bg (reference src/mimeo/wrappers.py:1131-1145): maximal runs of equal depth > 0 ----------------
+// The same events, sort and scan; a run begins at every distinct position where the depth differs from the depth in
+// front of it (equal depths on either side of a position — one interval ends where another begins — are one run, as
+// genomecov reports per-base depth), and ends at the next such position.
+__global__ void k7_change_flags(const int32_t *__restrict__ udep, const unsigned long long *__restrict__ nu_dev, uint8_t *__restrict__ flag, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint64_t nu = *nu_dev;
+    flag[i] = (i < nu && udep[i] != (i ? udep[i - 1] : 0)) ? 1 : 0;
+}
+__global__ void k7_runs(const uint64_t *__restrict__ bkey, const int32_t *__restrict__ bdep, const unsigned long long *__restrict__ nb_dev,
+                        mimeo_depth_run *__restrict__ out, uint8_t *__restrict__ keep, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const uint64_t nb = *nb_dev;
+    const bool k = i + 1 < nb && bdep[i] > 0;   // the last change of all goes down to depth 0
+    keep[i] = k ? 1 : 0;
+    if (k) out[i] = mimeo_depth_run{(uint32_t)(bkey[i] >> 32), (uint32_t)bkey[i], (uint32_t)bkey[i + 1], (uint32_t)bdep[i]};
+}
+
+int coverage_bedgraph_device(const mimeo_interval *h_iv, uint64_t n, const uint32_t *h_chrom_len, uint32_t nchrom,
+                             std::vector<mimeo_depth_run> &out) {
+    out.clear();
+    if (!n) return 0;
+    hipStream_t st = stream();
+    DeviceBuf iv, cl, k1, k2, d1, d2, dep, rows, rows2, cnt, tmp, fl;
+    struct Cleanup {
+        DeviceBuf *bufs[12];
+        ~Cleanup() { for (DeviceBuf *x : bufs) x->release(); }
+    } cleanup{{&iv, &cl, &k1, &k2, &d1, &d2, &dep, &rows, &rows2, &cnt, &tmp, &fl}};
+    int rc = 0;
+    const uint64_t ne = 2 * n;
+    if ((rc = iv.reserve(n * sizeof(mimeo_interval))) || (rc = cl.reserve((size_t)(nchrom ? nchrom : 1) * 4)) ||
+        (rc = k1.reserve(ne * 8)) || (rc = k2.reserve(ne * 8)) || (rc = d1.reserve(ne * 4)) || (rc = d2.reserve(ne * 4)) ||
+        (rc = dep.reserve(ne * 4)) || (rc = rows.reserve(ne * sizeof(mimeo_depth_run))) || (rc = rows2.reserve(ne * sizeof(mimeo_depth_run))) ||
+        (rc = cnt.reserve(32)) || (rc = fl.reserve(ne)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(iv.p, h_iv, n * sizeof(mimeo_interval), hipMemcpyHostToDevice, st));
+    if (nchrom) HIP_TRY(hipMemcpyAsync(cl.p, h_chrom_len, (size_t)nchrom * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, 32, st));
+    hipLaunchKernelGGL(k7_events, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const mimeo_interval *)iv.p, n,
+                       (const uint32_t *)cl.p, nchrom, (uint64_t *)k1.p, (int32_t *)d1.p);
+    unsigned long long *c_nu = (unsigned long long *)cnt.p, *c_nb = c_nu + 1, *c_rows = c_nu + 2;
+    uint64_t *ukey = (uint64_t *)k1.p;
+    int32_t *udep = (int32_t *)d1.p;
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)k1.p, (uint64_t *)k2.p, (int32_t *)d1.p, (int32_t *)d2.p, (size_t)ne, 0, 64, st));
+    HIP_TRY(rocprim::inclusive_scan(nullptr, t2, (int32_t *)d2.p, (int32_t *)dep.p, (size_t)ne, rocprim::plus<int32_t>(), st));
+    HIP_TRY(rocprim::select(nullptr, t3, (uint64_t *)k2.p, (uint8_t *)fl.p, ukey, c_nu, (size_t)ne, st));
+    HIP_TRY(rocprim::select(nullptr, t4, (int32_t *)dep.p, (uint8_t *)fl.p, udep, c_nu, (size_t)ne, st));
+    HIP_TRY(rocprim::select(nullptr, t5, (mimeo_depth_run *)rows.p, (uint8_t *)fl.p, (mimeo_depth_run *)rows2.p, c_rows, (size_t)ne, st));
+    if ((rc = tmp.reserve(std::max(std::max(std::max(t1, t2), std::max(t3, t4)), t5) + 16))) return rc;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)k1.p, (uint64_t *)k2.p, (int32_t *)d1.p, (int32_t *)d2.p, (size_t)ne, 0, 64, st));
+    HIP_TRY(rocprim::inclusive_scan(tmp.p, t2, (int32_t *)d2.p, (int32_t *)dep.p, (size_t)ne, rocprim::plus<int32_t>(), st));
+    const dim3 grd((uint32_t)((ne + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k7_last_flags, grd, blk, 0, st, (const uint64_t *)k2.p, ne, (uint8_t *)fl.p);
+    HIP_TRY(rocprim::select(tmp.p, t3, (uint64_t *)k2.p, (uint8_t *)fl.p, ukey, c_nu, (size_t)ne, st));
+    HIP_TRY(rocprim::select(tmp.p, t4, (int32_t *)dep.p, (uint8_t *)fl.p, udep, c_nu, (size_t)ne, st));
+    // positions where the depth changes, with the depth behind them
+    hipLaunchKernelGGL(k7_change_flags, grd, blk, 0, st, (const int32_t *)udep, (const unsigned long long *)c_nu, (uint8_t *)fl.p, ne);
+    uint64_t *bkey = (uint64_t *)k2.p;
+    int32_t *bdep = (int32_t *)dep.p;
+    HIP_TRY(rocprim::select(tmp.p, t3, ukey, (uint8_t *)fl.p, bkey, c_nb, (size_t)ne, st));
+    HIP_TRY(rocprim::select(tmp.p, t4, udep, (uint8_t *)fl.p, bdep, c_nb, (size_t)ne, st));
+    hipLaunchKernelGGL(k7_runs, grd, blk, 0, st, (const uint64_t *)bkey, (const int32_t *)bdep, (const unsigned long long *)c_nb,
+                       (mimeo_depth_run *)rows.p, (uint8_t *)fl.p, ne);
+    HIP_TRY(rocprim::select(tmp.p, t5, (mimeo_depth_run *)rows.p, (uint8_t *)fl.p, (mimeo_depth_run *)rows2.p, c_rows, (size_t)ne, st));
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, c_rows, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    out.resize(m);   // in (chrom, start) order: the select keeps the order of the sorted positions
+    if (m) HIP_TRY(hipMemcpy(out.data(), rows2.p, m * sizeof(mimeo_depth_run), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // namespace mimeo

@@ -157,6 +157,21 @@ def coverage_collapse(intervals, chrom_len, min_cov, min_len):
     return _ffi.take(ptr, n, _ffi.INTERVAL)
 
 
+def coverage_bedgraph(intervals, chrom_len):
+    """bedtools genomecov -bg: maximal runs of equal depth > 0 (records of _ffi.DEPTH_RUN, in chrom / start order)."""
+    iv = np.asarray(intervals)
+    if iv.dtype != _ffi.INTERVAL:
+        a = np.asarray(iv, dtype=np.uint32).reshape(-1, 3)
+        iv = np.zeros(a.shape[0], dtype=_ffi.INTERVAL)
+        iv['chrom'], iv['start'], iv['end'] = a[:, 0], a[:, 1], a[:, 2]
+    iv = np.ascontiguousarray(iv)
+    cl = np.ascontiguousarray(chrom_len, dtype=np.uint32)
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_coverage_bedgraph(iv.ctypes.data if iv.size else None, iv.size, cl.ctypes.data, cl.size,
+                                                   C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.DEPTH_RUN)
+
+
 def tandem_masked(A, intervals, match=2, mismatch=7, minscore=50, maxperiod=50, delta=7):
     """Bases of each (scaffold id, start, end) slice of genome A marked by the tandem scorer (K8)."""
     iv = np.asarray(intervals)

@@ -96,6 +96,32 @@ def coverage_collapse(intervals, chromlens, min_cov, min_len):
     return out
 
 
+def genomecov_bg(intervals, chromlens):
+    """wrappers.py:1131-1140 `bedtools genomecov -bg -i sorted.bed -g lens` alone, restated per base: the maximal
+    runs of equal depth > 0 (genomecov reports per-base depth, so a position where one interval ends and another
+    begins does not split a run).  Returns [(chrom, start, end, depth)] in (chrom, start) order."""
+    per = {}
+    for c, s, e in intervals:
+        per.setdefault(c, []).append((int(s), int(e)))
+    out = []
+    for c in sorted(per, key=lambda x: x.encode() if isinstance(x, str) else x):
+        L = int(chromlens[c])
+        diff = np.zeros(L + 1, dtype=np.int64)
+        for s, e in per[c]:
+            e = min(e, L)
+            if s >= e:
+                continue
+            diff[s] += 1
+            diff[e] -= 1
+        depth = np.concatenate(([0], np.cumsum(diff[:L]), [0]))
+        change = np.flatnonzero(np.diff(depth))      # depth[change + 1] holds from position `change` on
+        for a, b in zip(change[:-1], change[1:]):
+            d = int(depth[a + 1])
+            if d > 0:
+                out.append((c, int(a), int(b), d))
+    return out
+
+
 def gff_self_lines(regions, label, prefix, source='mimeo-self'):
     """wrappers.py:1153-1177 (x: :870-894, source 'mimeo'): header + one row per region, ID counter
     in output order, start written un-shifted."""
