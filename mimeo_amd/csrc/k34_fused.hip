@@ -294,19 +294,35 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), st = inc - c;
                 for (uint32_t rb = 0; rb < tot; rb += DQ) {
-                    if (c && st < rb + DQ && st + c > rb) {
+                    if (!(A.dbg & 8u) && c && st < rb + DQ && st + c > rb) {
+                        // a probe's range holds one or two entries nearly always (0.3 on average on a C4 tile, the empty ones
+                        // are not in nmask): they are written outright, the loop is for the rest; a range that straddles the
+                        // window of this round is clipped entry by entry
                         uint32_t acc = st;
+                        const uint32_t wend = rb + DQ;
                         for (uint32_t m = nmask; m; m &= m - 1u) {
                             const uint32_t j = (uint32_t)__builtin_ctz(m);
                             const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
                             const uint32_t a = max((uint32_t)sQ[w2], qs), b = min((uint32_t)sQ[w2 + 1], qe);
-                            const uint32_t g0 = max(acc, rb), g1 = min(acc + (b - a), rb + DQ);
-                            for (uint32_t g = g0; g < g1; g++) sD[g - rb] = (lane << 16) | (a + (g - acc) - qs);
-                            acc += b - a;
+                            const uint32_t cnt = b - a, d0 = (lane << 16) | (a - qs);
+                            if (acc >= rb && acc + cnt <= wend) {
+                                uint32_t *dst = sD + (acc - rb);
+                                dst[0] = d0;
+                                if (cnt > 1) {
+                                    dst[1] = d0 + 1u;
+#pragma unroll 1
+                                    for (uint32_t k = 2; k < cnt; k++) dst[k] = d0 + k;
+                                }
+                            } else {
+                                const uint32_t g0 = max(acc, rb), g1 = min(acc + cnt, wend);
+#pragma unroll 1
+                                for (uint32_t g = g0; g < g1; g++) sD[g - rb] = d0 + (g - acc);
+                            }
+                            acc += cnt;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    const uint32_t n = min(DQ, tot - rb);
+                    const uint32_t n = (A.dbg & 4u) ? 0u : min(DQ, tot - rb);   // development: 4 = no pair rounds, 8 = no descriptors either
                     for (uint32_t i = 0; i < n; i += 64) {
                         const bool valid = i + lane < n;
                         const uint32_t d = valid ? sD[i + lane] : 0u;

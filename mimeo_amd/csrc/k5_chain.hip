@@ -175,7 +175,7 @@ __device__ __forceinline__ void chain_tail(Group &G, mimeo_hsp *__restrict__ hs,
 }
 
 // groups beyond CH_BIG HSPs are left to k5_chain_big when skip_big is set
-constexpr uint32_t CH_BIG = 8192;
+constexpr uint32_t CH_BIG = 32768;
 __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ groups,
                                                        mimeo_hsp *__restrict__ hs, long long *__restrict__ best,
                                                        long long *__restrict__ cand, int *__restrict__ pred,
