@@ -155,8 +155,11 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     for (uint32_t t : tset) small_t += A->scaf[t].len <= member_max;
     for (uint32_t q : qset) small_q += QG->scaf[q].len <= member_max;
     if (std::max(small_t, small_q) < pack_min) return 0;
-    const bool self = (A == QG);
-    if (self && tset != qset) return 0;   // the main diagonals need target and query of a scaffold in ONE super-scaffold
+    // one genome, the same scaffolds in both roles: the two roles share the super-scaffolds, and the main diagonals stay
+    // with k4_diag0.  A subset of the targets against all scaffolds (a rank's share of a self job, dist.py) packs the two
+    // roles separately: a scaffold's main diagonal is then an ordinary diagonal of its unit, whose seed hits are resolved
+    // as the followers of its first one — the general rule, which k4_diag0 only short-cuts.
+    const bool self = (A == QG) && tset == qset;
     const uint32_t spacer = (uint32_t)std::max(64, p->xdrop / 100 + 32);
     SuperSide side_t, side_q;
     int rc = build_super_side(A, tset, spacer, member_max, super_len, side_t);

@@ -72,6 +72,23 @@ def test_packed_self_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
     g.close()
 
 
+def test_packed_share_of_a_self_job_equals_the_unit_per_pair_path(eng, monkeypatch):
+    """A rank's share of a self job (mimeo_amd/dist.py: some targets against every scaffold): target and query roles are
+    packed separately, so a scaffold's main diagonal goes through the general follower rule instead of k4_diag0."""
+    names, seqs = _fragmented(13, 20, 20 * 20_000)
+    g = eng.Genome(names, seqs)
+    pairs = [(t, q) for t in (1, 2, 3, 7, 8, 12, 19) for q in range(20)]
+    _clear(monkeypatch)
+    monkeypatch.setenv('MIMEO_PACK', '0')
+    ref = eng.align_pairs(g, None, pairs)
+    _clear(monkeypatch)
+    a = eng.align_pairs(g, None, pairs)
+    st = eng.stats()
+    assert st['super_units'] == 2 and ref.size > 20
+    assert _digest(a) == _digest(ref)
+    g.close()
+
+
 def test_packed_interspecies_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
     rng = np.random.Generator(np.random.PCG64(11))
     fams = make_families(rng, 6, (200, 1200))
