@@ -192,8 +192,24 @@ struct ExtBatch {
     hipEvent_t side_done = nullptr;
     std::vector<unsigned long long> h_unit_hits;
     double boost = 1.0;  // queue sizing: largest excess over the random-sequence shares seen so far
+    // run = start (the heavy phase of the batch is enqueued on the calling thread's stream, nothing is waited for) + finish
+    // (tails on the calling thread's stream at that time, which may be another one: two host round trips; a batch whose queues
+    // overflowed is repeated there with room).  The pipeline starts the next batch before it finishes this one.
     int run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp, ExtStats *st);
+    int start(const std::vector<UnitWork> &work, const mimeo_params *p);
+    int finish(uint64_t *nhsp, ExtStats *st);
     void release();
+    // state of the batch between start and finish
+    std::vector<UnitWork> w_;
+    mimeo_params p_;
+    std::vector<uint32_t> h_selfs_;
+    std::vector<UnitDesc> h_units_;
+    uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0, cap_w_ = 0;
+    double expect_hits_ = 0;
+    uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;
+    bool v1_ = false, started_ = false;
+    void *q_ = nullptr;   // ExtQueues of the batch (k4_device.h), owned
+    int enqueue_heavy();
 };
 // largest batch the follower key can name for scaffolds of these lengths (unit bits = 64 - end bits - diagonal bits)
 uint32_t ext_batch_max_units(uint64_t max_tlen, uint64_t max_qlen);

@@ -600,6 +600,9 @@ void ExtBatch::release() {
     kev.clear();
     if (side_done) { (void)hipEventDestroy(side_done); side_done = nullptr; }
     if (side) { (void)hipStreamDestroy(side); side = nullptr; }
+    delete (ExtQueues *)q_;
+    q_ = nullptr;
+    started_ = false;
 }
 
 static uint32_t bits_for(uint64_t v) {  // bits needed to hold values 0 .. v
@@ -615,16 +618,25 @@ uint32_t ext_batch_max_units(uint64_t max_tlen, uint64_t max_qlen) {
 }
 
 int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp_out, ExtStats *stats) {
-    hipStream_t st = stream();
     *nhsp_out = 0;
+    if (work.empty()) return 0;
+    int rc = start(work, p);
+    if (rc) return rc;
+    return finish(nhsp_out, stats);
+}
+
+int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p) {
+    hipStream_t st = stream();
+    started_ = false;
     const uint32_t nunits = (uint32_t)work.size();
     if (!nunits) return 0;
-    const uint32_t *tab = group_table_device();
-    if (!tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
+    w_ = work;
+    p_ = *p;
     uint64_t max_t = 0, max_q = 0;
     double expect_hits = 0, max_unit_hits = 0;
-    std::vector<UnitDesc> h_units(nunits);
-    std::vector<uint32_t> h_selfs;
+    std::vector<UnitDesc> &h_units = h_units_;   // a member: the copy below is asynchronous
+    h_units.resize(nunits);
+    h_selfs_.clear();
     for (uint32_t u = 0; u < nunits; u++) {
         const UnitWork &w = work[u];
         if (w.d.T.len >= 0x7FFFFF00u || w.d.Q.len >= 0x7FFFFF00u) { set_error("scaffold longer than 2^31 bases"); return MIMEO_ERR_LIMIT; }
@@ -633,32 +645,31 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         max_q = std::max<uint64_t>(max_q, w.d.Q.len);
         expect_hits += 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
         max_unit_hits = std::max(max_unit_hits, 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0);
-        if (w.d.same) h_selfs.push_back(u);
+        if (w.d.same) h_selfs_.push_back(u);
     }
-    ExtQueues q;
-    memset(&q, 0, sizeof q);
-    q.ebits = bits_for(max_t + SEED_LEN);
-    q.dbits = bits_for(max_t + max_q + SEED_LEN);
-    if (q.ebits + q.dbits > 63 || (nunits > 1 && bits_for(nunits - 1) + q.ebits + q.dbits > 64)) {
+    expect_hits_ = expect_hits;
+    ebits_ = bits_for(max_t + SEED_LEN);
+    dbits_ = bits_for(max_t + max_q + SEED_LEN);
+    if (ebits_ + dbits_ > 63 || (nunits > 1 && bits_for(nunits - 1) + ebits_ + dbits_ > 64)) {
         set_error("internal: batch too large for the follower key");
         return MIMEO_ERR_ARG;
     }
-    const uint32_t key_bits = std::min(64u, q.ebits + q.dbits + (nunits > 1 ? bits_for(nunits - 1) : 0));
+    key_bits_ = std::min(64u, ebits_ + dbits_ + (nunits > 1 ? bits_for(nunits - 1) : 0));
     if (!ev[0]) {
         for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     }
-    const bool v1 = getenv("MIMEO_HEAVY") && !strcmp(getenv("MIMEO_HEAVY"), "v1");
+    v1_ = getenv("MIMEO_HEAVY") && !strcmp(getenv("MIMEO_HEAVY"), "v1");
     int rc;
     if ((rc = units.reserve((size_t)nunits * sizeof(UnitDesc))) || (rc = ctr.reserve(sizeof(ExtCounters))) ||
         (rc = unit_hits.reserve((size_t)nunits * 8)) || (rc = nsel.reserve(16)) ||
-        (rc = tile_hits.reserve(v1 ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) || (rc = heavy.reserve(4096 * 4)) ||
+        (rc = tile_hits.reserve(v1_ ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) || (rc = heavy.reserve(4096 * 4)) ||
         (rc = bigacc.reserve((size_t)ENT_BIGCAP * 5 * 8)) ||
-        (rc = selfs.reserve((h_selfs.size() + 1) * 4)))
+        (rc = selfs.reserve((h_selfs_.size() + 1) * 4)))
         return rc;
     HIP_TRY(hipMemcpyAsync(units.p, h_units.data(), (size_t)nunits * sizeof(UnitDesc), hipMemcpyHostToDevice, st));
-    if (!h_selfs.empty()) HIP_TRY(hipMemcpyAsync(selfs.p, h_selfs.data(), h_selfs.size() * 4, hipMemcpyHostToDevice, st));
+    if (!h_selfs_.empty()) HIP_TRY(hipMemcpyAsync(selfs.p, h_selfs_.data(), h_selfs_.size() * 4, hipMemcpyHostToDevice, st));
     // Queue capacities from the hit count expected on random sequence; a batch that does not fit (repeat-rich
     // units) is repeated with room for everything the counters saw.  On random sequence 0.65 % of the hits
     // are followers, ~1 % outlive the frame and 1e-4 become candidates.
@@ -666,16 +677,34 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
     // `boost`: the largest excess over these shares that an earlier batch showed (a repeat-rich genome overflows the
     // first batch once, not every batch)
     // (followers and generic-walk hits: capacity PER SHARD, eight shards, with half as much again for their imbalance)
-    uint64_t cap_f = (uint64_t)(expect_hits * 0.02 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    uint64_t cap_m = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    uint64_t cap_l = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    uint64_t cap_c = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_f_ = (uint64_t)(expect_hits * 0.02 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_m_ = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_l_ = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_c_ = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
     // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
-    uint64_t cap_w = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    ExtCounters c;
-    uint64_t nf_total = 0, nm_total = 0;
-    float ms_heavy = 0, ms_tails = 0, ms_walk = 0, ms_k34 = 0;
-    for (int attempt = 0;; attempt++) {
+    cap_w_ = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    if (!q_) q_ = new ExtQueues();
+    if ((rc = enqueue_heavy())) return rc;
+    started_ = true;
+    return 0;
+}
+
+// the heavy phase of the batch on the calling thread's stream, with the current capacities
+int ExtBatch::enqueue_heavy() {
+    hipStream_t st = stream();
+    const uint32_t nunits = (uint32_t)w_.size();
+    const mimeo_params *p = &p_;
+    const uint32_t *tab = group_table_device();
+    if (!tab) { set_error("group table upload failed"); return MIMEO_ERR_HIP; }
+    ExtQueues &q = *(ExtQueues *)q_;
+    memset(&q, 0, sizeof q);
+    q.ebits = ebits_; q.dbits = dbits_;
+    const uint64_t cap_f = cap_f_, cap_m = cap_m_, cap_l = cap_l_, cap_c = cap_c_, cap_w = cap_w_;
+    const bool v1 = v1_;
+    const std::vector<UnitWork> &work = w_;
+    const std::vector<uint32_t> &h_selfs = h_selfs_;
+    int rc;
+    {
         if ((rc = fkey.reserve(cap_f * 8 * 8)) || (rc = fprev.reserve(cap_f * 8 * 4)) || (rc = medq.reserve(cap_m * 8 * 8)) ||
             (rc = medu.reserve(cap_m * 8 * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
             (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp))) ||
@@ -746,6 +775,33 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         }
         if (!v1) launch_sum_hits(q, nunits, st);
         HIP_TRY(hipEventRecord(ev[1], st));
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
+    *nhsp_out = 0;
+    if (!started_) return 0;
+    started_ = false;
+    hipStream_t st = stream();
+    const uint32_t nunits = (uint32_t)w_.size();
+    const mimeo_params *p = &p_;
+    const uint32_t *tab = group_table_device();
+    ExtQueues &q = *(ExtQueues *)q_;
+    const std::vector<UnitWork> &work = w_;
+    const std::vector<uint32_t> &h_selfs = h_selfs_;
+    const bool v1 = v1_;
+    const uint32_t key_bits = key_bits_;
+    const double expect_hits = expect_hits_;
+    const UnitDesc *d_units = (const UnitDesc *)units.p;
+    int rc;
+    ExtCounters c;
+    uint64_t nf_total = 0, nm_total = 0;
+    float ms_heavy = 0, ms_tails = 0, ms_walk = 0, ms_k34 = 0;
+    for (int attempt = 0;; attempt++) {
+        uint64_t &cap_f = cap_f_, &cap_m = cap_m_, &cap_l = cap_l_, &cap_c = cap_c_, &cap_w = cap_w_;
+        HIP_TRY(hipStreamWaitEvent(st, ev[1], 0));   // the heavy phase may have run on another stream
         // ---- tails, once per batch
         HIP_TRY(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k4_extend_generic, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh,
@@ -831,6 +887,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
         cap_c = std::max<uint64_t>(cap_c, 2 * c.ncand + 65536);
         cap_w = std::max<uint64_t>(cap_w, c.nwalk_over + c.nwalk_over / 4 + 1024);
         if (stats) stats->reruns++;
+        if ((rc = enqueue_heavy())) return rc;   // the batch again, on this stream, with room
     }
     h_unit_hits.resize(nunits);
     HIP_TRY(hipMemcpy(h_unit_hits.data(), unit_hits.p, (size_t)nunits * 8, hipMemcpyDeviceToHost));
