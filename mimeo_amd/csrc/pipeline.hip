@@ -90,7 +90,8 @@ struct IndexCache {
     }
 };
 
-static ExtBatch g_ext;
+static ExtBatch g_ext, g_ext2;   // two: the heavy phase of a batch is enqueued while the batch before it is finished
+static hipStream_t g_tail_stream = nullptr;   // tails, chain and gapped extension of a batch, beside the next batch's heavy phase
 static DeviceBuf g_scratch, g_aln, g_dense, g_groups;
 
 struct Unit {
@@ -101,6 +102,8 @@ struct Unit {
 // mimeo_shutdown: give the work buffers and streams back
 void release_pipeline_buffers() {
     g_ext.release();
+    g_ext2.release();
+    if (g_tail_stream) { (void)hipStreamDestroy(g_tail_stream); g_tail_stream = nullptr; }
     g_scratch.release();
     g_aln.release();
     g_dense.release();
@@ -401,62 +404,101 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             }
         }
         rc = cache.build_all();
+        // ---- the batches of this block
+        struct BatchPlan { size_t b0, b1; std::vector<UnitWork> work; std::vector<Group> groups; };
+        std::vector<BatchPlan> plan;
+        // MIMEO_OVERLAP=1 (measured, not the default): a block of 32 units or more is cut into at least four batches and a
+        // batch's tails, chain and gapped extension run on a second stream beside the heavy phase of the next batch (two
+        // sets of queues).  On a C4 row every stage stretches by what it overlaps — K34 215 -> 266 ms, gapped 44 -> 102 —
+        // and the row takes 356 ms instead of 344: the stages are throughput-bound on the same SIMDs, there is no idle
+        // resource to fill.  Kept for the record and for the identity test.
+        const bool overlap_ok = getenv("MIMEO_OVERLAP") && atoi(getenv("MIMEO_OVERLAP")) && !getenv("MIMEO_BATCH_UNITS");
+        size_t cut_units = max_units;
+        if (overlap_ok && blk_end - blk_begin >= 32) cut_units = std::min<size_t>(max_units, (blk_end - blk_begin + 3) / 4);
         for (size_t b0 = blk_begin; b0 < blk_end && !rc;) {
-            // ---- one batch: units b0 .. b1
-            std::vector<UnitWork> work;
-            std::vector<Group> groups;
+            BatchPlan bp;
             double hits = 0;
             size_t b1 = b0;
-            for (; b1 < blk_end && work.size() < max_units; b1++) {
+            for (; b1 < blk_end && bp.work.size() < cut_units; b1++) {
                 const Unit &u = units[b1];
                 const Scaffold &ts = A->scaf[u.tid], &qs = QG->scaf[u.qid];
                 UnitWork w;
                 memset(&w, 0, sizeof w);
                 if ((rc = cache.get(ts, 0, true, &w.ti, &w.d.T)) || (rc = cache.get(qs, (int)u.minus, false, &w.qi, &w.d.Q))) break;
                 const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
-                if (!work.empty() && hits + e > max_hits) break;
+                if (!bp.work.empty() && hits + e > max_hits) break;
                 hits += e;
                 w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1u : 0u;
-                work.push_back(w);
+                bp.work.push_back(w);
                 Group g;
                 memset(&g, 0, sizeof g);
                 g.T = w.d.T; g.Q = w.d.Q; g.tid = u.tid; g.qid = u.qid; g.minus = u.minus;
-                groups.push_back(g);
+                bp.groups.push_back(g);
             }
             if (rc) break;
-            uint64_t nh = 0;
-            static const bool timing = getenv("MIMEO_TIMING") != nullptr;   // development: host wall time of the phases of a batch
+            bp.b0 = b0; bp.b1 = b1;
+            plan.push_back(std::move(bp));
+            b0 = b1;
+        }
+        ExtBatch *ext[2] = {&g_ext, &g_ext2};
+        const bool overlap = !rc && plan.size() > 1 && overlap_ok;
+        hipStream_t s_tail = st;
+        if (overlap) {
+            if (!g_tail_stream) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = the numerically lowest = highest priority
+                if (hipStreamCreateWithPriority(&g_tail_stream, hipStreamNonBlocking, hi) != hipSuccess) { set_error("hipStreamCreateWithPriority failed"); rc = MIMEO_ERR_HIP; }
+            }
+            s_tail = g_tail_stream;
+        }
+        static const bool timing = getenv("MIMEO_TIMING") != nullptr;   // development: host wall time of the phases of a batch
+        if (!rc && !plan.empty()) rc = ext[0]->start(plan[0].work, p);
+        for (size_t k = 0; k < plan.size() && !rc; k++) {
+            BatchPlan &bp = plan[k];
+            std::vector<Group> &groups = bp.groups;
+            const size_t b0 = bp.b0, b1 = bp.b1;
             auto tb0 = std::chrono::steady_clock::now();
-            if ((rc = g_ext.run(work, p, &nh, &est))) break;
+            if (!overlap && k) {
+                if ((rc = ext[0]->start(bp.work, p))) break;
+            } else if (overlap && k + 1 < plan.size()) {   // the next batch's heavy phase is in the queue before this one's tails are waited for
+                set_thread_stream(st);
+                if ((rc = ext[(k + 1) & 1]->start(plan[k + 1].work, p))) break;
+            }
+            set_thread_stream(s_tail);
+            hipStream_t sk = stream();
+            ExtBatch &X = *ext[overlap ? (k & 1) : 0];
+            uint64_t nh = 0;
+            if ((rc = X.finish(&nh, &est))) break;
             auto tb1 = std::chrono::steady_clock::now();
-            g_stats.pair_strands += work.size();
+            g_stats.pair_strands += bp.work.size();
             g_stats.hsps += nh;
             for (size_t i = b0; i < b1; i++) g_stats.query_bases_scanned += QG->scaf[units[i].qid].len;
             g_stats.batches++;
             if (nh) {
                 if ((rc = g_groups.reserve(groups.size() * sizeof(Group))) || (rc = g_aln.reserve(nh * sizeof(mimeo_alignment)))) break;
-                if (hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st) != hipSuccess) {
+                if (hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, sk) != hipSuccess) {
                     set_error("hipMemcpyAsync(groups) failed");
                     rc = MIMEO_ERR_HIP;
                     break;
                 }
-                if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_ext.hsps.p,
-                                              (const uint32_t *)g_ext.hsp_unit.p, nh, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain,
+                if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)X.hsps.p,
+                                              (const uint32_t *)X.hsp_unit.p, nh, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain,
                                               &ms_gapped)))
                     break;
                 // the alignments are a few thousand records in an array of one slot per HSP: packed on the device, then read
                 if ((rc = g_dense.reserve(nh * sizeof(mimeo_alignment)))) break;
                 dense_alignments_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_alignment *)g_aln.p,
                                         (mimeo_alignment *)g_dense.p);
-                if (hipMemcpyAsync(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) {
+                if (hipMemcpyAsync(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, sk) != hipSuccess ||
+                    hipStreamSynchronize(sk) != hipSuccess) {
                     set_error("HIP error while reading back alignments");
                     rc = MIMEO_ERR_HIP;
                     break;
                 }
                 const uint64_t naln_total = (uint64_t)groups.back().job0 + groups.back().naln;
                 std::vector<mimeo_alignment> host_aln(naln_total);
-                if (naln_total && hipMemcpy(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost) != hipSuccess) {
+                if (naln_total && (hipMemcpyAsync(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost, sk) != hipSuccess ||
+                                   hipStreamSynchronize(sk) != hipSuccess)) {
                     set_error("HIP error while reading back alignments");
                     rc = MIMEO_ERR_HIP;
                     break;
@@ -481,12 +523,13 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             }
             if (timing) {
                 auto tb2 = std::chrono::steady_clock::now();
-                fprintf(stderr, "[timing] batch of %zu units: extension stage %.2f ms (device heavy %.2f + tails %.2f), chain + gapped + read-back %.2f ms (device %.2f + %.2f)\n",
-                        work.size(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(), est.ms_heavy, est.ms_tails,
+                fprintf(stderr, "[timing] batch of %zu units%s: next start + tails %.2f ms (device heavy %.2f + tails %.2f so far), chain + gapped + read-back %.2f ms (device %.2f + %.2f so far)\n",
+                        bp.work.size(), overlap ? " (overlapped)" : "", std::chrono::duration<double, std::milli>(tb1 - tb0).count(), est.ms_heavy, est.ms_tails,
                         std::chrono::duration<double, std::milli>(tb2 - tb1).count(), ms_chain, ms_gapped);
             }
-            b0 = b1;
         }
+        set_thread_stream(nullptr);
+        if (rc) { (void)hipStreamSynchronize(st); if (g_tail_stream) (void)hipStreamSynchronize(g_tail_stream); }   // a started batch drains
         cache.clear();
         ms_index += cache.ms;
         g_stats.index_blocks++;

@@ -258,6 +258,33 @@ def test_pipeline_modes_give_identical_alignments(eng, monkeypatch):
     g.close()
 
 
+def test_overlapped_batches_give_identical_alignments(eng, monkeypatch):
+    """MIMEO_OVERLAP=1: a call of 32 units or more is cut into at least four batches, and the tails / chain / gapped stage of a
+    batch run on a second stream beside the heavy phase of the next one (two sets of queues).  Same bytes as one batch after
+    the other (the default: measured faster)."""
+    import hashlib
+    n, s = synth_genome(78, 1_800_000, 6, repeat_frac=0.08, families=6, cons_len=(300, 2500))
+    g = eng.Genome(n, s)
+    pairs = [(t, q) for t in range(6) for q in range(6)]
+    outs = {}
+    for tag, env in (('overlap', {'MIMEO_OVERLAP': '1'}), ('no_overlap', {}), ('overlap_rerun', {'MIMEO_OVERLAP': '1', 'MIMEO_QUEUE_SHRINK': '3000'})):
+        for k in ('MIMEO_OVERLAP', 'MIMEO_QUEUE_SHRINK', 'MIMEO_BATCH_UNITS', 'MIMEO_PACK'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = eng.align_pairs(g, None, pairs)
+        st = eng.stats()
+        outs[tag] = (a.size, hashlib.md5(a.tobytes()).hexdigest(), st['seed_hits'], st['hsps'])
+        assert st['pair_strands'] == 72
+        assert st['batches'] == (1 if tag == 'no_overlap' else 4), (tag, st['batches'])
+        if tag == 'overlap_rerun':
+            assert st['queue_reruns'] >= 1
+    for k in ('MIMEO_OVERLAP', 'MIMEO_QUEUE_SHRINK'):
+        monkeypatch.delenv(k, raising=False)
+    assert len(set(outs.values())) == 1 and outs['overlap'][0] > 30, outs
+    g.close()
+
+
 def test_kept_seed_indexes_are_reused_and_change_nothing(eng):
     """mimeo_genome_keep_indexes: a job issued row by row (one call per target scaffold) gives the
     records of the single call, later calls build nothing, dropped scaffolds are rebuilt."""
