@@ -136,3 +136,30 @@ def test_packed_alignments_match_the_oracle(eng, monkeypatch):
     bad = np.flatnonzero(got[cols] != exp[cols])
     assert bad.size == 0, (got[cols][bad[:5]], exp[cols][bad[:5]])
     g.close()
+
+
+def test_fragmented_self_workflow_files_do_not_depend_on_packing(eng, tmp_path, monkeypatch):
+    """`mimeo self` end to end on a fragmented genome (40 scaffolds of uneven size, one above the member limit): TAB and
+    GFF3 written with super-scaffolds and one unit per pair are the same bytes."""
+    from mimeo_amd import workflow
+    names, seqs = synth_genome(31, 40 * 15_000, 40, repeat_frac=0.2, families=6, cons_len=(200, 1200), max_div=0.1)
+    rng = np.random.default_rng(31)
+    for i in range(40):
+        seqs[i] = seqs[i][:len(seqs[i]) - int(rng.integers(0, 6000))].copy()
+    names = ['ctg%d' % (97 * i % 40) for i in range(40)]   # C-locale order differs from FASTA order
+    A = eng.Genome(names, seqs)
+    pairs = workflow.all_pairs(40)
+    outs = {}
+    for tag, env in (('packed', {'MIMEO_PACK_MEMBER': '14500'}), ('unit_per_pair', {'MIMEO_PACK': '0'})):
+        _clear(monkeypatch)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outtab, outgff = str(tmp_path / (tag + '.tab')), str(tmp_path / (tag + '.gff3'))
+        workflow.self_repeats(A, pairs, outtab, outgff, minIdt=80, minLen=100, minCov=3, label='Self_Repeat', prefix='Self_Repeat')
+        st = eng.stats()
+        assert (st['super_units'] > 0) == (tag == 'packed')
+        outs[tag] = (open(outtab).read(), open(outgff).read())
+    _clear(monkeypatch)
+    assert outs['packed'] == outs['unit_per_pair']
+    assert outs['packed'][0].count('\n') > 100 and outs['packed'][1].count('\n') > 3
+    A.close()
