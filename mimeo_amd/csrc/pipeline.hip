@@ -93,6 +93,8 @@ struct IndexCache {
 static ExtBatch g_ext, g_ext2;   // two: the heavy phase of a batch is enqueued while the batch before it is finished
 static hipStream_t g_tail_stream = nullptr;   // tails, chain and gapped extension of a batch, beside the next batch's heavy phase
 static DeviceBuf g_scratch, g_aln, g_dense, g_groups;
+// tables of the packed path (run_packed)
+static DeviceBuf d_toff, d_tstart, d_tlen, d_trank, d_qoff, d_qstart, d_qlen, d_qrank, d_pairidx, d_pt, d_pq, d_tview, d_qvf, d_qvr, d_utab;
 
 struct Unit {
     uint64_t pair;  // index into pair_t / pair_q
@@ -108,6 +110,8 @@ void release_pipeline_buffers() {
     g_aln.release();
     g_dense.release();
     g_groups.release();
+    for (DeviceBuf *b : {&d_toff, &d_tstart, &d_tlen, &d_trank, &d_qoff, &d_qstart, &d_qlen, &d_qrank, &d_pairidx, &d_pt, &d_pq, &d_tview, &d_qvf, &d_qvr, &d_utab})
+        b->release();
     release_pack_buffers();
 }
 
@@ -185,7 +189,6 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     *used = true;
     hipStream_t st = stream();
     // ---- device tables
-    static DeviceBuf d_toff, d_tstart, d_tlen, d_trank, d_qoff, d_qstart, d_qlen, d_qrank, d_pairidx, d_pt, d_pq, d_tview, d_qvf, d_qvr, d_utab;
     auto member_tables = [&](const SuperSide &S, const std::vector<uint32_t> &rank, std::vector<uint32_t> &off, std::vector<uint32_t> &start,
                              std::vector<uint32_t> &len, std::vector<uint32_t> &rk) {
         off.assign(1, 0u);
