@@ -181,17 +181,15 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         const uint32_t *toff = A.T.off + (size_t)tile * TILE_WORDS, *qoff = A.Q.off + (size_t)tile * TILE_WORDS;
         const uint32_t t0 = toff[0], nT = toff[TILE_WORDS] - t0;
         const uint32_t q0 = qoff[0], nQ = qoff[TILE_WORDS] - q0;
-        if (!nT || !nQ) {
-            if (threadIdx.x == 0 && !HEAVY) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = 0ull;
-            return;
-        }
+        if (!nT || !nQ) return;   // tile_hits is zeroed per batch
         if (HEAVY && blockIdx.z * QSEG >= nQ) return;   // no query segment for this share
         if (!HEAVY) {
-            // The tile's hit count up front (K3's counting pass, per tile: both offset arrays pass through the frame area of
-            // LDS once): it is the statistic, and a tile with far more hits than the average — a microsatellite's seed
-            // words: thousands of entries of ONE key on both sides, 10^7-10^8 hits in one tile — or with more query entries
-            // than 16-bit offsets can name is not worked off by one workgroup while the chip waits: it is listed for the
-            // split pass.
+            // A tile with far more hits than the average — a microsatellite's seed words: thousands of entries of ONE key on both
+            // sides, 10^7-10^8 hits in one tile — or with more query entries than 16-bit offsets can name is not worked off by
+            // one workgroup while the chip waits: it is listed for the split pass.  The test is an ESTIMATE made up front from
+            // the exact-key hits alone (one probe per word instead of thirteen; both offset arrays pass through the frame area
+            // of LDS once): 13 x sum nT(w) nQ(w).  Which pass takes a tile changes nothing in the results; the exact count of a
+            // tile — the seed_hits statistic — is the sum of the pairs its chunk visits enumerate (below).
             uint32_t *sT = reinterpret_cast<uint32_t *>(sQF), *sQ32 = sT + TILE_WORDS + 4;
             {
                 const uint4 *s0 = reinterpret_cast<const uint4 *>(toff), *s1 = reinterpret_cast<const uint4 *>(qoff);
@@ -201,22 +199,25 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             }
             __syncthreads();
             unsigned long long cnt = 0;
-            for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS) {
-                const uint32_t nt = sT[w + 1] - sT[w];
-                if (nt) {
-                    uint32_t sum = sQ32[w + 1] - sQ32[w];
-                    if (A.transitions)
-                        for (int j = 0; j < SEED_WEIGHT; j++) { const uint32_t w2 = w ^ (1u << j); sum += sQ32[w2 + 1] - sQ32[w2]; }
-                    cnt += (unsigned long long)nt * sum;
-                }
-            }
+            for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS)
+                cnt += (unsigned long long)(sT[w + 1] - sT[w]) * (sQ32[w + 1] - sQ32[w]);
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
             if (lane == 0 && cnt) atomicAdd(s_total, cnt);
             __syncthreads();
-            const unsigned long long tile_total = *s_total;
-            if (threadIdx.x == 0) A.q.tile_hits[(size_t)A.unit * NTILE + tile] = tile_total;
-            if (!tile_total) return;
-            if (tile_total > HEAVY_HITS || nQ > 0xFFFFu) {
+            if (!*s_total && A.transitions) {   // no exact-key hit (sparse tiles of small scaffolds): any hit at all?  Otherwise the tile is done
+                __syncthreads();
+                unsigned long long c2 = 0;
+                for (uint32_t w = threadIdx.x; w < TILE_WORDS; w += THREADS) {
+                    const uint32_t nt = sT[w + 1] - sT[w];
+                    if (nt)
+                        for (int j = 0; j < SEED_WEIGHT; j++) { const uint32_t w2 = w ^ (1u << j); c2 += sQ32[w2 + 1] - sQ32[w2]; }
+                }
+                if (__syncthreads_or(c2 != 0) == 0) return;
+            } else if (!*s_total) {
+                return;
+            }
+            const unsigned long long tile_est = *s_total * (A.transitions ? (unsigned long long)(SEED_WEIGHT + 1) : 1ull);
+            if (tile_est > HEAVY_HITS || nQ > 0xFFFFu) {
                 if (threadIdx.x == 0) A.q.heavy[atomicAdd(&A.q.ctr->nheavy, 1ull)] = tile;   // at most NTILE entries
                 return;
             }
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             const uint32_t e = ch_first * TCH + lane;
             if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
         }
+        unsigned long long hits_acc = 0;   // pairs this wavefront enumerates in this tile (wave-uniform): the tile's exact hit count
         const uint32_t qs_first = HEAVY ? blockIdx.z * QSEG : 0u, qs_step = (HEAVY ? gridDim.z : 1u) * QSEG;
         for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
             const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
                 inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
                 const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), st = inc - c;
+                hits_acc += tot;
                 for (uint32_t rb = 0; rb < tot; rb += DQ) {
                     if (!(A.dbg & 8u) && c && st < rb + DQ && st + c > rb) {
                         // a probe's range holds one or two entries nearly always (0.3 on average on a C4 tile, the empty ones
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 }
             }
         }
+        if (lane == 0 && hits_acc) atomicAdd(&A.q.tile_hits[(size_t)A.unit * NTILE + tile], hits_acc);
     };
 
     if (!HEAVY) {

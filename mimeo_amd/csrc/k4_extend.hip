@@ -731,6 +731,7 @@ int ExtBatch::enqueue_heavy() {
         const UnitDesc *d_units = (const UnitDesc *)units.p;
         HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(ExtCounters), st));
         HIP_TRY(hipMemsetAsync(unit_hits.p, 0, (size_t)nunits * 8, st));
+        if (!v1) HIP_TRY(hipMemsetAsync(tile_hits.p, 0, (size_t)nunits * NTILE * 8, st));   // K34 adds to it: a tile's pairs, wavefront by wavefront
         HIP_TRY(hipMemsetAsync(nsel.p, 0, 16, st));
         HIP_TRY(hipMemsetAsync(bigacc.p, 0, (size_t)ENT_BIGCAP * 5 * 8, st));
         HIP_TRY(hipEventRecord(ev[0], st));
