@@ -6,7 +6,8 @@
 // stores for 0.62 GB of records), K4 read them back and gathered 13 eight-byte words around every hit through L2
 // — to prove for 95 % of them that nothing comes of them.  Here no hit is stored unless it matters:
 //   * both seed indexes are CSR in the transition-closed key layout (common.h): a workgroup owns one tile of 4096
-//     keys, stages the query tile's offsets in LDS (16 KiB) and resolves all 13 probes of a word there (K3's join);
+//     keys, stages the query tile's offsets in LDS (relative to the tile, 16 bits each: 8 KiB) and resolves all 13 probes of a
+//     word there (K3's join);
 //   * every index entry carries its seed FRAME (K2: 192 bases around the seed start, both planes, one common
 //     alignment), so a tile's frames are contiguous: the query frames are STREAMED into LDS, coalesced, in segments
 //     of QSEG entries, and each wavefront keeps the frames of 64 target entries in registers (one entry per lane,
@@ -16,9 +17,10 @@
 //     Poisson(7.8) on a C4 unit); a lane takes one pair, fetches the target frame from its owner lane
 //     (ds_bpermute) and the query frame from LDS, and runs the pre-filter: twelve XORs bring the two frames
 //     together, every shift of the popcount bounds and of the earlier-seed-hit test is a compile-time constant;
-//   * the ~1.5 % of the pairs the filter cannot dismiss go, compacted per wavefront (ballot + prefix count), to the
-//     batch's walk queue (k4_walk_queue: the exact walk, once per batch).
-// HBM traffic per unit: the two offset arrays, and positions + frames of both sides ONCE (52 bytes per entry).
+//   * the ~4 % of the pairs the filter cannot dismiss go, compacted per wavefront (ballot + prefix count), to the
+//     unit's walk queue (k4_extend_hits on the queue: sharp filter + exact walk, right behind this kernel).
+// HBM traffic per unit: the two offset arrays, positions + frames of both sides once (52 bytes per entry), and the target
+// frames of a tile once more per further query segment (Infinity Cache).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
