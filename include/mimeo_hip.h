@@ -237,6 +237,14 @@ int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q,
  * align target scaffold pair_t[k] of A against query scaffold pair_q[k] of B
  * (B == NULL: of A, i.e. `mimeo self`).  Results are concatenated in pair order;
  * the host applies the awk/sort filter (A11) when it writes the TAB.
+ *
+ * How the pairs are worked off is the library's business and changes no record: units
+ * (target, query, strand) in batches; when the list is a full cross product with at least 16
+ * scaffolds of at most 2 Mbp on one side, the small scaffolds are concatenated behind spacers
+ * of N into super-scaffolds for the seed index and the gap-free stage, and every HSP is handed
+ * back to its scaffold pair before chaining and gapped extension (mimeo_stats.super_units > 0;
+ * DESIGN.md "Fragmented assemblies").  Limits: scaffolds below 2^31 - 256 bases; a gapped
+ * alignment scoring beyond 2^31 or a DP band beyond 65 536 columns is MIMEO_ERR_LIMIT.
  */
 int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t,
                       const uint32_t *pair_q, uint64_t npairs, const mimeo_params *p,
