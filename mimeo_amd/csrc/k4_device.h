@@ -105,7 +105,7 @@ static inline int host_sub(int dl, int dh, int cg) {
     static const int lo[4] = {91, 100, -31, -31}, hi[4] = {-114, -114, -123, -125};
     return (dl ? hi : lo)[(dh << 1) | cg];
 }
-static void build_group_table(uint32_t *tab) {
+static inline void build_group_table(uint32_t *tab) {
     for (int idx = 0; idx < GROUP_TAB; idx++) {
         int p = 0, M = -100000, mn = 100000, posM = 0;
         for (int k = 0; k < 4; k++) {

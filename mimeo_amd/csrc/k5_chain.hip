@@ -229,7 +229,7 @@ __global__ __launch_bounds__(CH_THREADS) void k5_chain(Group *__restrict__ group
 // over 2048 members when the HSP starts behind all of them in the target, tile by tile (exactly k5_chain's step)
 // otherwise.  32 times fewer passes; predecessors and ties as in k5_chain: the maximum over the eligible members of a
 // block with the smallest member on ties is what its 32 tiles, visited in order with strict improvements, arrive at.
-constexpr uint32_t CH_BLOCK = 2048, CH_SUB = CH_BLOCK / CH_TILE;
+constexpr uint32_t CH_BLOCK = 2048;   // 32 tiles
 constexpr size_t CH_BIG_LDS = (size_t)CH_BLOCK * 48 + 1024;
 __global__ __launch_bounds__(CH_THREADS) void k5_chain_big(Group *__restrict__ groups, const uint32_t *__restrict__ big_list,
                                                            const unsigned int *__restrict__ nbig, mimeo_hsp *__restrict__ hs,
