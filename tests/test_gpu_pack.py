@@ -163,3 +163,33 @@ def test_fragmented_self_workflow_files_do_not_depend_on_packing(eng, tmp_path, 
     assert outs['packed'] == outs['unit_per_pair']
     assert outs['packed'][0].count('\n') > 100 and outs['packed'][1].count('\n') > 3
     A.close()
+
+
+def test_cli_self_two_ranks_on_a_fragmented_genome(tmp_path):
+    """`mimeo self` under torchrun (two gloo ranks sharing GPU 0) on a fragmented genome: every rank takes some targets
+    against all scaffolds (dist.shard_pairs_by_target) — a full cross product, packed — and rank 0 writes the same TAB /
+    GFF3 as a single process."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from mimeo_amd.synth import write_fasta
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names, seqs = synth_genome(41, 36 * 12_000, 36, repeat_frac=0.2, families=5, cons_len=(200, 1200), max_div=0.1)
+    fa = str(tmp_path / 'frag.fa')
+    write_fasta(fa, names, seqs)
+    args = ['self', '--afasta', fa, '--minIdt', '80', '--minLen', '100', '--minCov', '3']
+    env1 = {k: v for k, v in os.environ.items() if not k.startswith('MIMEO_PACK')}
+    one = subprocess.run([sys.executable, '-m', 'mimeo_amd'] + args + ['-d', str(tmp_path / 'one')], cwd=root, capture_output=True, text=True,
+                         timeout=600, env=env1)
+    assert one.returncode == 0, one.stdout + one.stderr
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env2 = dict(env1, MIMEO_DIST_BACKEND='gloo', MIMEO_FORCE_DEVICE='0')
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), '-m', 'mimeo_amd'] + args + ['-d', str(tmp_path / 'two')], cwd=root, capture_output=True,
+                         text=True, timeout=900, env=env2)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    for f in ('mimeo_alignment.tab', 'mimeo-self_repeats.gff3', 'A_gen_lens.txt'):
+        a, b = (tmp_path / 'one' / f).read_text(), (tmp_path / 'two' / f).read_text()
+        assert a == b, f
+    assert (tmp_path / 'one' / 'mimeo_alignment.tab').read_text().count('\n') > 50
