@@ -239,8 +239,8 @@ int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q,
  * the host applies the awk/sort filter (A11) when it writes the TAB.
  *
  * How the pairs are worked off is the library's business and changes no record: units
- * (target, query, strand) in batches; when the list is a full cross product with at least 16
- * scaffolds of at most 2 Mbp on one side, the small scaffolds are concatenated behind spacers
+ * (target, query, strand) in batches; when the list is a full cross product with at least eight
+ * scaffolds of at most 6 Mbp on one side (and no kept indexes), they are concatenated behind spacers
  * of N into super-scaffolds for the seed index and the gap-free stage, and every HSP is handed
  * back to its scaffold pair before chaining and gapped extension (mimeo_stats.super_units > 0;
  * DESIGN.md "Fragmented assemblies").  Limits: scaffolds below 2^31 - 256 bases; a gapped

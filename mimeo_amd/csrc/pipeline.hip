@@ -134,7 +134,8 @@ int ungapped_units(const std::vector<UnitWork> &work, const mimeo_params *p, std
 
 // ---- fragmented assemblies: the extension stage on super-scaffolds (pack.hip) ------------------------------------------
 // Taken when the pair list is a full cross product T x Q (what every mimeo workflow asks for) with at least
-// MIMEO_PACK_MIN (16) scaffolds of at most MIMEO_PACK_MEMBER (2 Mbp) bases on one side; MIMEO_PACK=0 switches it off.
+// MIMEO_PACK_MIN (8) scaffolds of at most MIMEO_PACK_MEMBER (6 Mbp) bases on one side and no kept indexes; MIMEO_PACK=0
+// switches it off.
 // *used = false: the caller runs the unit-per-pair path.
 template <typename T>
 static int upload(DeviceBuf &b, const std::vector<T> &v) {
@@ -150,9 +151,14 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     *used = false;
     if (getenv("MIMEO_PACK") && !atoi(getenv("MIMEO_PACK"))) return 0;
     if (npairs == 0 || npairs >= (1ull << 30)) return 0;
-    const uint64_t member_max = getenv("MIMEO_PACK_MEMBER") ? (uint64_t)atol(getenv("MIMEO_PACK_MEMBER")) : (2ull << 20);
-    const uint64_t super_len = getenv("MIMEO_PACK_SUPER") ? (uint64_t)atol(getenv("MIMEO_PACK_SUPER")) : (8ull << 20);
-    const size_t pack_min = getenv("MIMEO_PACK_MIN") ? (size_t)atol(getenv("MIMEO_PACK_MIN")) : 16;
+    // K34 works a 10 Mbp x 10 Mbp unit off at 13.5 ps per seed hit, a 5 Mbp x 5 Mbp one at 21.7, a 2 Mbp x 2 Mbp one at 117 (4096
+    // tiles to stage whatever the scaffold size): scaffolds of up to 6 Mbp are packed into super-scaffolds of about 20 Mbp
+    // when there are at least eight of them (C2, ten scaffolds of 5 Mbp: 144 -> 106 ms per job).
+    const uint64_t member_max = getenv("MIMEO_PACK_MEMBER") ? (uint64_t)atol(getenv("MIMEO_PACK_MEMBER")) : (6ull << 20);
+    const uint64_t super_len = getenv("MIMEO_PACK_SUPER") ? (uint64_t)atol(getenv("MIMEO_PACK_SUPER")) : (20ull << 20);
+    const size_t pack_min = getenv("MIMEO_PACK_MIN") ? (size_t)atol(getenv("MIMEO_PACK_MIN")) : 8;
+    // indexes kept on a genome handle say that the caller issues the job as many calls (a row per call): they are used
+    if (A->keep_indexes || QG->keep_indexes) return 0;
     host_plan::CrossProduct cp = host_plan::cross_product(pair_t, pair_q, npairs, A->scaf.size(), QG->scaf.size());
     const std::vector<uint32_t> &tset = cp.tset, &qset = cp.qset, &trank = cp.trank, &qrank = cp.qrank, &pairidx = cp.pairidx;
     const std::vector<std::pair<uint64_t, uint64_t>> &dups = cp.dups;   // (duplicate, first occurrence): answered from the first
