@@ -5,16 +5,22 @@ Default workload = the configuration BASELINE.json's metric is quoted on: C4, `m
 synthetic genome (100 scaffolds x 10 Mbp, 5 % planted repeats, seed 1000), --minIdt 80 --minLen 100
 --minCov 3.  It fits one GPU (packed genome 1.5 GB + 117 GB of seed indexes with their seed frames, in 288 GB).
 
-A "step" (row mode, workloads c4 / c4small) = one TARGET scaffold per rank through the whole hot path:
-the seed indexes of that scaffold are (re)built (both strands), the scaffold is aligned as target against
-all S query scaffolds x 2 strands (seed scan, gap-free extension, chain, gapped extension: 2*S units =
-1/S of the job's S^2 ordered pairs), the A11 filter and the coverage-depth collapse of that target run
-(coverage is per target, src/mimeo/wrappers.py:1131-1150), and the filtered records and regions of all
-ranks are concatenated by an all-gatherv (RCCL).  Rank r takes rows r, r+N, r+2N, ...: S/N steps on N GPUs
-are exactly the job run_jobs.sh does in the reference (wrappers.py:1015-1177), every seed index built once.
-The packed genome and the seed indexes of the other scaffolds are resident in HBM when the timed region
-starts.  Per-GPU work is fixed as N grows: "scaling" is "weak"; value = target bases completed by all ranks
-per second = (1 Gbp genome) / (time the whole job takes at that rate).
+A "step" (row mode, workloads c4 / c4small) = one TARGET ROW per rank through the whole hot path = 1/S of
+the job's 2 S^2 (target, query, strand) units (mimeo_amd/dist.py units_of_row): the seed indexes of that
+scaffold are (re)built (both strands); it is aligned as target against all S query scaffolds on the minus
+strand and against itself on the plus strand; and the plus-strand units of the (S-1)/2 unordered scaffold
+pairs dealt to this row are aligned ONCE and emitted for both orders — (t, q, +) and (q, t, +) have
+transposed HSP sets, so the engine shares their seed scan and gap-free stage (mimeo_align_units; chain and
+gapped extension run per ordered pair).  S rows name every unit of the job exactly once.  Then the A11
+filter runs and the kept records of all ranks are concatenated by an all-gatherv (RCCL); the coverage-depth
+collapse (per target, src/mimeo/wrappers.py:1131-1150) runs ONCE over the records of all timed steps,
+inside the timed region, after the last step — a target's plus-strand records now come from several rows.
+Rank r takes rows r, r+N, r+2N, ...: S/N steps on N GPUs are exactly the job run_jobs.sh does in the
+reference (wrappers.py:1015-1177), every seed index built once.  The packed genome and the seed indexes of
+the other scaffolds are resident in HBM when the timed region starts (the H2D copy of the packed genome,
+1 GB = ~16 ms + 6 ms of K1 per job, is outside: stated in the line).  Per-GPU work is fixed as N grows:
+"scaling" is "weak"; value = target bases completed by all ranks per second = (1 Gbp genome) / (time the
+whole job takes at that rate).
 
 Job mode (workloads c2, small, c3, c5, ...: the other BASELINE configs, development aids): a step is the
 whole job, pairs sharded over ranks, "scaling" "strong" (the round-1 bench line for C2 is kept in profiles/).
@@ -104,8 +110,8 @@ def cpu_oracle_times(pair_jobs, threads=1):
 
 
 def host_cores():
-    # at most 16 threads: the CPU share of a one-GPU box, and it keeps this leg near half a minute
-    return min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    """every host core this process may run on (all host cores, count recorded)"""
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
 
 def cpu_baseline_job(names, seqs, self_pair, cross_pair):
@@ -120,14 +126,14 @@ def cpu_baseline_job(names, seqs, self_pair, cross_pair):
     out = {'value': total_bp / 1e9 / total_s, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
            'sample': 'pairs %d-%d (%.1f s) and %d-%d (%.1f s) of %d ordered pairs; whole job extrapolated as '
                      'S*t_self + (S*S-S)*t_cross = %.0f s' % (self_pair + (times[0],) + cross_pair + (times[1], S * S, total_s))}
-    cores = host_cores()
+    cores = min(host_cores(), 16)   # job mode: whole pairs are minutes of oracle time each; sixteen of them at once
     if cores > 1 and S > 1:
         sample = [(t, q) for t in range(S) for q in range(S) if t != q][:cores]
         bufs = [seqs[i].tobytes() for i in range(S)]
         wall = cpu_oracle_times([(bufs[t], bufs[q]) for t, q in sample], threads=len(sample))
         per_pair = wall / len(sample)  # effective seconds per cross pair with all cores busy
         mt_s = (S * S - S) * per_pair + S * times[0] / min(cores, S)
-        out['allcores'] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': len(sample), 'kind': 'port',
+        out['cores%d' % len(sample)] = {'value': total_bp / 1e9 / mt_s, 'unit': 'Gbp-aligned/s', 'cores': len(sample), 'kind': 'port',
                            'sample': '%d cross pairs run concurrently on %d threads in %.1f s; whole job extrapolated to %.0f s'
                                      % (len(sample), len(sample), wall, mt_s)}
     return out
@@ -148,24 +154,30 @@ def host_description():
 
 
 def cpu_baseline_rows(seqs, samples=32, slice_bp=400_000, seed=8):
-    """Row mode (C4), SURVEY §8d: `samples` seeded-random (target scaffold, query scaffold) pairs, the oracle built
-    -O3 -march=native on this box, run on all host cores at once (one pair per thread) and, for the like-for-like
-    figure of the reference's serial script, the per-pair cost of one core.  A whole 10 Mbp x 10 Mbp pair takes the
-    oracle about a minute, so a sample aligns the whole target against a random `slice_bp` window of the query, both
-    strands; seed hits — and with them the time — grow with Lt x Lq, so a pair costs Lq / slice_bp samples."""
+    """Row mode (C4), SURVEY §8d: seeded-random (target scaffold, query scaffold) pairs — at least `samples`, and at least one
+    per host core —, the oracle built -O3 -march=native on this box, run on ALL host cores this process may use at once (one
+    job per thread; `allcores.cores` says how many) and, for the like-for-like figure of the reference's serial script, the
+    per-job cost of one core over FOUR of the samples.  A whole 10 Mbp x 10 Mbp pair takes the oracle about a minute, so a
+    sample aligns the whole target against a random `slice_bp` window of the query, both strands; seed hits — and with them
+    the time — grow with Lt x Lq, so a pair costs Lq / slice_bp samples."""
     from oracle import oracle as O
     native = O.use_native_build()
     rng = np.random.Generator(np.random.PCG64(seed))
     S, L = len(seqs), len(seqs[0])
     sl = min(slice_bp, L)
+    cores = host_cores()
+    samples = max(samples, cores)
+    tbytes = {}
     jobs = []
     for _ in range(samples):
         t, q = int(rng.integers(0, S)), int(rng.integers(0, S))
         o = int(rng.integers(0, L - sl + 1))
-        jobs.append((seqs[t].tobytes(), seqs[q][o:o + sl].tobytes()))
-    cores = host_cores()
+        if t not in tbytes:
+            tbytes[t] = seqs[t].tobytes()
+        jobs.append((tbytes[t], seqs[q][o:o + sl].tobytes()))
     wall_mt = cpu_oracle_times(jobs, threads=cores)
-    one = cpu_oracle_times(jobs[:2]) / 2                       # one core, two of the samples
+    nsingle = min(4, len(jobs))
+    one = cpu_oracle_times(jobs[:nsingle]) / nsingle           # one core, four of the samples
     pairs = S * S
     per_pair_1 = one * (L / sl)
     total_1 = per_pair_1 * pairs
@@ -173,12 +185,12 @@ def cpu_baseline_rows(seqs, samples=32, slice_bp=400_000, seed=8):
     total_bp = S * L
     host = host_description()
     out = {'value': total_bp / 1e9 / total_1, 'unit': 'Gbp-aligned/s', 'cores': 1, 'kind': 'port',
-           'sample': '2 of the %d sampled (scaffold, %.1f Mbp query window) jobs on one core: %.1f s each; a 10 Mbp x 10 Mbp pair = %.0f such '
+           'sample': '%d of the %d sampled (scaffold, %.1f Mbp query window) jobs on one core: %.1f s each; a 10 Mbp x 10 Mbp pair = %.0f such '
                      'windows, the job %d ordered pairs: %.0f s extrapolated; oracle/ built %s'
-                     % (samples, sl / 1e6, one, L / sl, pairs, total_1, '-O3 -march=native on this box' if native else '-O3 (portable build)'),
+                     % (nsingle, samples, sl / 1e6, one, L / sl, pairs, total_1, '-O3 -march=native on this box' if native else '-O3 (portable build)'),
            'host': host}
     out['allcores'] = {'value': total_bp / 1e9 / total_mt, 'unit': 'Gbp-aligned/s', 'cores': cores, 'kind': 'port',
-                       'sample': '%d seeded-random (target, query window) jobs on %d threads in %.1f s; whole job extrapolated to %.0f s'
+                       'sample': '%d seeded-random (target, query window) jobs on %d threads (every core this process may use) in %.1f s; whole job extrapolated to %.0f s'
                                  % (samples, cores, wall_mt, total_mt)}
     return out
 
@@ -215,6 +227,28 @@ def pmc_traffic(workload):
         return int(1024 * (2 * d[key + '_FETCH_SIZE_KB_per_launch']['k34_scan_extend'] + d[key + '_WRITE_SIZE_KB_per_launch']['k34_scan_extend']))
     except Exception:
         return None
+
+
+def valu_issue(avg_launch_ms):
+    """What bounds K34: VALU issue.  insts_per_launch = SQ_INSTS_VALU of a first-pass launch on a C4 unit
+    (profiles/r03_pmc_k34_sq.json); cycles_per_inst_mix = its opcode mix from the ISA priced with the measured per-opcode issue
+    rates (scripts/k34_isa_mix.py -> profiles/r03_k34_isa_mix.json, profiles/r03_valu_rate.txt); frac_of_issue_peak = the
+    share of the 1024 SIMDs' issue time those instructions take at this run's launch duration."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_k34_isa_mix.json')) as f:
+            mix = json.load(f)
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_k34_sq.json')) as f:
+            pmc = json.load(f)['kernels']['k34_scan_extend (first pass)']
+        insts, c = pmc['SQ_INSTS_VALU'], mix['cycles_per_inst_mix']
+        return {'insts_per_launch': insts, 'cycles_per_inst_mix': c,
+                'frac_of_issue_peak': insts * c / (1024 * avg_launch_ms * 1e-3 * 2.4e9) if avg_launch_ms > 0 else None,
+                'full_rate_share_of_valu': mix['dynamic_c4_unit']['full_rate_share_of_valu'],
+                'issue_cycles_at_2.4GHz': {k: mix['issue_cycles_at_2.4GHz'][k] for k in ('full_rate_class', 'half_rate_class')},
+                'lanes_active_per_valu_inst': mix['dynamic_c4_unit'].get('lanes_active_per_valu_inst'),
+                'source': 'profiles/r03_pmc_k34_sq.json (SQ_INSTS_VALU per first-pass launch, C4 unit), profiles/r03_k34_isa_mix.json (ISA opcode mix), '
+                          'profiles/r03_valu_rate.txt (cycles per opcode, MI355X)'}
+    except Exception as e:
+        return {'error': repr(e)}
 
 
 def standalone_seed_scan(engine, A, tq):
@@ -284,16 +318,19 @@ def main():
             iv['chrom'], iv['start'], iv['end'] = cid_of_tid[a['tid']], a['tstart'] + 1, a['tend']
         return iv
 
+    kept_rows = []
+
     def step_row():
-        """One target scaffold per rank: indexes of that scaffold, 2*S units, A11 filter, collapse, gather."""
+        """One target row per rank: indexes of that scaffold, its 2*S units (plus-strand pairs shared), A11 filter, gather."""
+        from mimeo_amd.dist import units_of_row
         t = row_of(step_no[0], dist.world, dist.rank, nscaf)
         step_no[0] += 1
         A.drop_indexes([t])
-        alns = engine.align_pairs(A, None, [(t, q) for q in range(nscaf)], params)
+        alns = engine.align_units(A, None, units_of_row(t, nscaf), params)
         st = engine.stats()
-        a = a11_filter(alns, MIN_LEN, MIN_IDT)
-        regions = engine.coverage_collapse(intervals_of(a), lens_sorted, MIN_COV, MIN_LEN)
-        return st, dist.allgather_records(a), dist.allgather_records(regions)
+        a = dist.allgather_records(a11_filter(alns, MIN_LEN, MIN_IDT))
+        kept_rows.append(a)
+        return st, a, None
 
     def step_job():
         alns = engine.align_pairs(A, B, mine, params) if mine else np.zeros(0, dtype=_ffi.ALIGNMENT)
@@ -319,6 +356,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    del kept_rows[:]
     sync()
     t0 = time.time()
     agg = {}
@@ -329,6 +367,11 @@ def main():
             agg[k] = agg.get(k, 0) + v
         n_aln += int(alns.size)
         n_reg += int(regions.size) if regions is not None else 0
+    if kind == 'row' and dist.rank == 0:
+        # the coverage collapse of everything the timed rows produced (a whole job: of every target), once, inside the timed region
+        a = np.concatenate(kept_rows) if kept_rows else np.zeros(0, dtype=_ffi.ALIGNMENT)
+        regions = engine.coverage_collapse(intervals_of(a), lens_sorted, MIN_COV, MIN_LEN)
+        n_reg = int(regions.size)
     sync()
     dt = dist.max_float(time.time() - t0)
     ms_per_step = 1000.0 * dt / max(1, args.steps)
@@ -349,9 +392,12 @@ def main():
         if kind == 'row':
             # target bases completed by all ranks per second; S/N such steps are the whole job
             value = dist.world * (total_bp / nscaf) / 1e9 / (ms_per_step / 1e3)
-            what = ('a step = one target scaffold per rank x all %d query scaffolds x 2 strands (%d units = 1/%d of the %d ordered pairs), '
-                    'its seed indexes rebuilt, A11 filter + coverage collapse of that target, records all-gathered; rows dealt round-robin'
-                    % (nscaf, 2 * nscaf, nscaf, len(pairs)))
+            what = ('a step = one target row per rank = %d units = 1/%d of the job (%d ordered pairs x 2 strands): the row\'s %d minus-strand units, '
+                    'its own plus-strand unit and the plus-strand units of the unordered pairs dealt to it, each computed once and emitted for both '
+                    'orders (shared seed scan and gap-free stage); its seed indexes rebuilt, A11 filter, records all-gathered; the coverage collapse '
+                    'runs once over the records of all timed steps, inside the timed region; rows dealt round-robin; packed genome and the other '
+                    'scaffolds\' indexes resident (H2D of the genome, ~22 ms per job, outside the timed region)'
+                    % (2 * nscaf, nscaf, len(pairs), nscaf))
             par = 'target rows x%d (no data-path collective; all-gatherv of records)' % dist.world
         else:
             value = total_bp / 1e9 / (ms_per_step / 1e3)
@@ -369,14 +415,16 @@ def main():
                                       scaf_mbp, seed if B is None else '%d/%d' % (seed, seed_b), what),
                        'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': par},
             'roofline': {'kernel': 'k34_scan_extend (seed scan fused with the gap-free pre-filter; one launch per (target, query, strand) unit)',
-                         'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                         'bound': 'valu', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                         'valu': valu_issue(t_fill * 1e3) if args.workload in ('c4', 'c4job') else None,
                          'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
                          'traffic_frac': (traffic / t_fill / 8e12) if (traffic and t_fill > 0) else None,
                          'kernel_bytes_per_launch': agg['scan_bytes_kernel'] / launches,
                          'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches),
-                         'note': 'achieved = SURVEY 8(d) B_scan per unit / HIP-event duration of the launch.  The fused kernel never writes the hit '
-                                 'array the byte model charges for, and it is bound by VALU issue of the pre-filter (popcounts, funnel shifts), not '
-                                 'by HBM: traffic_frac is what it really moves; frac_standalone is the seed scan alone.',
+                         'note': 'achieved / peak / frac = the HBM roofline SURVEY 8(d) defines: B_scan per unit / HIP-event duration of the launch / 8 TB/s.  '
+                                 'The fused kernel never writes the hit array that byte model charges for; what bounds it is VALU issue of the '
+                                 'pre-filter (bound = valu; the valu block: instructions per launch x cycles per instruction of its opcode mix / '
+                                 'issue time of the 1024 SIMDs).  traffic_frac is what it really moves; frac_standalone is the seed scan alone (K3).',
                          'frac_standalone': standalone},
             'stage_ms_per_step_rank0': {k: round(agg[k] / max(1, args.steps), 3) for k in ('ms_index', 'ms_scan', 'ms_scan_fill', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_total')},
             'stage_note': 'ms_scan = heavy phase (K34 + the walk-queue kernel per unit), ms_scan_fill = the K34 launches alone, ms_extend = tails once per batch; K34 timed region includes nothing else: inputs (packed genome, seed indexes of the other scaffolds) are resident in HBM, the H2D of the genome (1 GB, ~16 ms + 6 ms K1 per 50 s job) is outside',

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MIMEO_ABI_VERSION 2
+#define MIMEO_ABI_VERSION 3
 
 enum {
     MIMEO_OK = 0,
@@ -243,12 +243,36 @@ int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q,
  * scaffolds of at most 6 Mbp on one side (and no kept indexes), they are concatenated behind spacers
  * of N into super-scaffolds for the seed index and the gap-free stage, and every HSP is handed
  * back to its scaffold pair before chaining and gapped extension (mimeo_stats.super_units > 0;
- * DESIGN.md "Fragmented assemblies").  Limits: scaffolds below 2^31 - 256 bases; a gapped
- * alignment scoring beyond 2^31 or a DP band beyond 65 536 columns is MIMEO_ERR_LIMIT.
+ * DESIGN.md "Fragmented assemblies"); in a self job (B == NULL) the plus-strand units of (t, q) and
+ * (q, t) share one seed scan and gap-free stage when neither scaffold has soft-masked bases (DESIGN.md
+ * "Shared plus strand").  Limits: scaffolds below 2^31 - 256 bases.  A pair whose gapped extension
+ * scores beyond 2^31 or needs a DP band beyond 65 536 columns is LEFT OUT — no row of it is returned,
+ * the other pairs are, the call returns 0 and mimeo_get_failed_pairs names the pair: the reference's
+ * run_jobs.sh has no `set -e`, a failing lastz run costs its own pair's rows only (utils.py:125-128,
+ * :194-210 look at the last command's status).
  */
 int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t,
                       const uint32_t *pair_q, uint64_t npairs, const mimeo_params *p,
                       mimeo_alignment **out, uint64_t *nout);
+
+/*
+ * The same loop with the strands chosen per pair: pair k is aligned on the strands pair_strand[k]
+ * (MIMEO_STRAND_PLUS | MIMEO_STRAND_MINUS, masked with p->strand; pair_strand == NULL: p->strand for every
+ * pair, i.e. mimeo_align_pairs).  This is what a rank's share of a sharded self job looks like
+ * (mimeo_amd/dist.py deal_units): all minus-strand units of its target rows, and the plus-strand units
+ * of the unordered scaffold pairs dealt to it in BOTH orders, so that the shared plus strand applies.
+ * Results are concatenated in pair order, a pair's plus-strand rows first.
+ */
+int mimeo_align_units(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t,
+                      const uint32_t *pair_q, const uint8_t *pair_strand, uint64_t npairs,
+                      const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
+
+/*
+ * Pairs of the last mimeo_align_pairs / mimeo_align_units call that hit a documented limit and were left
+ * out: *n of them; the first min(*n, cap) are written to pair_index[] (index into the call's pair list)
+ * and code[] (MIMEO_ERR_LIMIT).  Either array may be NULL.  mimeo_last_error() describes the last one.
+ */
+int mimeo_get_failed_pairs(uint64_t *pair_index, int32_t *code, uint64_t cap, uint64_t *n);
 
 /*
  * bedtools genomecov -bg | awk $4>=min_cov | sort | bedtools merge | awk len>=min_len

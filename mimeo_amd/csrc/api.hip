@@ -21,6 +21,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     char buf[512];
     snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
     g_err = buf;
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return MIMEO_ERR_NOMEM; }   // not sticky: the caller may retry smaller
     return MIMEO_ERR_HIP;
 }
 // a worker thread of the library may run its launches on a stream of its own
@@ -312,14 +313,34 @@ int mimeo_align_pairs(const mimeo_genome *A, const mimeo_genome *B, const uint32
     if (rc) return rc;
     if (!A || !p || !out || !nout || (npairs && (!pair_t || !pair_q))) { set_error("null argument"); return MIMEO_ERR_ARG; }
     if ((rc = check_params(p))) return rc;
-    return align_pairs_impl(A, B, pair_t, pair_q, npairs, p, out, nout);
+    return align_units_impl(A, B == A ? nullptr : B, pair_t, pair_q, nullptr, npairs, p, out, nout);
+}
+
+int mimeo_align_units(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+                      const uint8_t *pair_strand, uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!A || !p || !out || !nout || (npairs && (!pair_t || !pair_q))) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    if ((rc = check_params(p))) return rc;
+    return align_units_impl(A, B == A ? nullptr : B, pair_t, pair_q, pair_strand, npairs, p, out, nout);
+}
+
+int mimeo_get_failed_pairs(uint64_t *pair_index, int32_t *code, uint64_t cap, uint64_t *n) {
+    if (!n) { set_error("null argument"); return MIMEO_ERR_ARG; }
+    const auto &f = failed_pairs();
+    *n = f.size();
+    for (uint64_t i = 0; i < f.size() && i < cap; i++) {
+        if (pair_index) pair_index[i] = f[i].first;
+        if (code) code[i] = f[i].second;
+    }
+    return MIMEO_OK;
 }
 
 int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, const mimeo_params *p,
                      mimeo_alignment **out, uint64_t *nout) {
     int rc = check_pair(T, tid, Q, qid, p, out, nout);
     if (rc) return rc;
-    return align_pairs_impl(T, Q, &tid, &qid, 1, p, out, nout);
+    return align_units_impl(T, Q == T ? nullptr : Q, &tid, &qid, nullptr, 1, p, out, nout);
 }
 
 int mimeo_coverage_collapse(const mimeo_interval *iv, uint64_t n, const uint32_t *chrom_len, uint32_t nchrom,

@@ -191,26 +191,38 @@ struct ExtBatch {
     hipStream_t side = nullptr;      // k4_diag0 of the self units runs beside the heavy kernels
     hipEvent_t side_done = nullptr;
     std::vector<unsigned long long> h_unit_hits;
-    double boost = 1.0;  // queue sizing: largest excess over the random-sequence shares seen so far
+    // queue sizing: largest excess over the random-sequence shares seen so far, per queue (followers, walks beyond the frame,
+    // long walks, candidates, walk queue): microsatellites flood the follower queue alone (C5: half of all hits)
+    double boost_f = 1.0, boost_m = 1.0, boost_l = 1.0, boost_c = 1.0, boost_w = 1.0;
     // run = start (the heavy phase of the batch is enqueued on the calling thread's stream, nothing is waited for) + finish
     // (tails on the calling thread's stream at that time, which may be another one: two host round trips; a batch whose queues
     // overflowed is repeated there with room).  The pipeline starts the next batch before it finishes this one.
-    int run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp, ExtStats *st);
-    int start(const std::vector<UnitWork> &work, const mimeo_params *p);
+    // mirror_dst (optional, one entry per unit): unit u's HSPs are also emitted transposed (target <-> query) for unit
+    // mirror_dst[u] (NO_MIRROR: none).  The plus-strand units (A, B) and (B, A) of a self job have transposed HSP sets —
+    // seeds, x-drop walks, the per-diagonal rule, entropy and HOXD70 are all symmetric — so one heavy phase serves both
+    // (DESIGN.md "Shared plus strand"); the mirror unit itself comes with empty indexes and launches nothing.
+    // MIMEO_ERR_SPLIT (internal): the queues of this batch do not fit the free device memory — the caller cuts it in two.
+    int run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp, ExtStats *st, const std::vector<uint32_t> *mirror_dst = nullptr);
+    int start(const std::vector<UnitWork> &work, const mimeo_params *p, const std::vector<uint32_t> *mirror_dst = nullptr);
     int finish(uint64_t *nhsp, ExtStats *st);
     void release();
     // state of the batch between start and finish
     std::vector<UnitWork> w_;
     mimeo_params p_;
-    std::vector<uint32_t> h_selfs_;
+    std::vector<uint32_t> h_selfs_, mirror_dst_;
     std::vector<UnitDesc> h_units_;
+    DeviceBuf mirror;     // mirror_dst_ on the device + one counter
     uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0, cap_w_ = 0;
     double expect_hits_ = 0;
     uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;
     bool v1_ = false, started_ = false;
     void *q_ = nullptr;   // ExtQueues of the batch (k4_device.h), owned
     int enqueue_heavy();
+    uint64_t queue_bytes() const;   // device bytes the queues of the batch take at the current capacities
+    uint64_t held_bytes() const;    // ... and what its buffers hold already
 };
+constexpr uint32_t NO_MIRROR = 0xFFFFFFFFu;
+constexpr int MIMEO_ERR_SPLIT = -100;   // internal: never crosses the C-ABI
 // largest batch the follower key can name for scaffolds of these lengths (unit bits = 64 - end bits - diagonal bits)
 uint32_t ext_batch_max_units(uint64_t max_tlen, uint64_t max_qlen);
 
@@ -257,6 +269,7 @@ struct RegroupTables {   // device pointers
 int regroup_hsps_device(mimeo_hsp *d_hsps, uint32_t *d_hunit, uint64_t nh, const RegroupTables &R, uint32_t npairs, DeviceBuf &groups,
                         uint32_t *ngroups);
 int group_summary_device(const Group *d_groups, uint32_t ngroups, uint64_t out[3]);
+int overflowed_groups_device(const Group *d_groups, uint32_t ngroups, uint64_t expect, std::vector<uint2> *out);
 void release_pack_buffers();
 // chain + gapped extension of every group (pipeline.hip)
 int chain_gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_hsps, const uint32_t *d_hsp_unit, uint64_t nhsps,
@@ -270,9 +283,11 @@ int coverage_bedgraph_device(const mimeo_interval *h_iv, uint64_t n, const uint3
 int coverage_collapse_device(const mimeo_interval *h_iv, uint64_t n, const uint32_t *h_chrom_len, uint32_t nchrom,
                              uint32_t min_cov, uint32_t min_len, std::vector<mimeo_interval> &out, float *ms);
 
-// whole-job loop (pipeline.hip)
-int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
-                     uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
+// whole-job loop (pipeline.hip): pair k on the strands pair_strand[k] (null: p->strand for every pair)
+int align_units_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+                     const uint8_t *pair_strand, uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout);
+// pairs of the last align call that hit a documented limit (their rows are left out, the call goes on): (pair index, code)
+const std::vector<std::pair<uint64_t, int>> &failed_pairs();
 
 void release_pipeline_buffers();  // pipeline.hip
 int ungapped_units(const std::vector<UnitWork> &work, const mimeo_params *p, std::vector<std::vector<mimeo_hsp>> *per_unit,

@@ -54,6 +54,7 @@ inline CrossProduct cross_product(const uint32_t *pair_t, const uint32_t *pair_q
     for (size_t i = 0; i < c.qset.size(); i++) c.qrank[c.qset[i]] = (uint32_t)i;
     const size_t nq = c.qset.size();
     if (nq && c.tset.size() > (size_t)0xFFFFFFF0u / nq) return c;   // more cells than a pair index can name: not taken
+    if (c.tset.size() * nq > n) return c;   // fewer pairs than cells: cannot be the full product (a sparse list would cost |T| x |Q| cells to find out)
     c.pairidx.assign(c.tset.size() * nq, 0xFFFFFFFFu);
     for (uint64_t k = 0; k < n; k++) {
         uint32_t &slot = c.pairidx[(size_t)c.trank[pair_t[k]] * nq + c.qrank[pair_q[k]]];

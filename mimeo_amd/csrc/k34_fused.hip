@@ -131,16 +131,17 @@ __device__ __forceinline__ uint4 bperm4(uint32_t src_lane, const uint4 v) {
                       (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.z), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.w));
 }
 
-// LDS of a workgroup: the query tile's offsets (relative to its first entry: 16 bits each in the first pass, which
-// leaves tiles of 65536 query entries and more to the split pass), QSEG query frames (three 16-byte parts), one
-// descriptor queue and one walk staging area per wavefront, the N flags of the segment.  First pass: 512 threads, two
+// LDS of a workgroup: the query tile's offsets RELATIVE TO THE CURRENT SEGMENT and clamped to it (16 bits each: a key's
+// range inside the segment is sQ[w] .. sQ[w + 1] whatever the size of the tile — one code path for tiles of one segment
+// and of many, in both passes; rewritten from the offset array, L2-resident, for every segment), QSEG query frames
+// (three 16-byte parts), one descriptor queue and one walk staging area per wavefront, the N flags of the segment.  First pass: 512 threads, two
 // workgroups per CU, QSEG = 1280 (79 KiB each): the 2441 entries of an average C4 tile are two segments — every target
 // chunk is visited once per segment (frames, key, 13 probes, prefix sum, descriptors: ~530 instructions for the
 // visit), so three segments of 1024 cost a third more visits for the same pairs.
 template <int THREADS, uint32_t QSEG, bool HEAVY>
 struct FusedCfg {
     static constexpr int WAVES = THREADS / 64;
-    static constexpr size_t OFF_BYTES = ((TILE_WORDS + 1) * (HEAVY ? 4 : 2) + 15) / 16 * 16;
+    static constexpr size_t OFF_BYTES = ((TILE_WORDS + 1) * 2 + 15) / 16 * 16;
     static constexpr size_t SMEM = OFF_BYTES + (size_t)QSEG * 48 + (size_t)WAVES * DQ * 4 + (size_t)WAVES * 64 * 8 + QSEG + 16;
 };
 
@@ -149,7 +150,7 @@ struct FusedCfg {
 template <int THREADS, uint32_t QSEG, bool HEAVY>
 __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
     using Cfg = FusedCfg<THREADS, QSEG, HEAVY>;
-    using qoff_t = typename std::conditional<HEAVY, uint32_t, uint16_t>::type;
+    using qoff_t = uint16_t;
     constexpr int WAVES = THREADS / 64;
     static_assert((size_t)QSEG * 48 >= 2 * (TILE_WORDS + 4) * 4, "the count prologue stages both offset arrays in the frame area");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -219,16 +220,11 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 return;
             }
             const unsigned long long tile_est = *s_total * (A.transitions ? (unsigned long long)(SEED_WEIGHT + 1) : 1ull);
-            if (tile_est > HEAVY_HITS || nQ > 0xFFFFu) {
+            if (tile_est > HEAVY_HITS || nQ > 0xFFFFu) {   // (a tile of 65536 query entries and more: 52 segments for one workgroup)
                 if (threadIdx.x == 0) A.q.heavy[atomicAdd(&A.q.ctr->nheavy, 1ull)] = tile;   // at most NTILE entries
                 return;
             }
-            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] = (qoff_t)(sQ32[k] - q0);   // relative to the tile's first query entry
-            __syncthreads();   // ... before the frames overwrite the staged offsets
-        } else {
-            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) sQ[k] = qoff[k] - q0;
         }
-        const bool single = nQ <= QSEG;   // the whole query tile in one segment: no clipping of the neighbour ranges
         const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
         const uint32_t nchunks = (nT + TCH - 1) / TCH;
         // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
@@ -244,7 +240,12 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         const uint32_t qs_first = HEAVY ? blockIdx.z * QSEG : 0u, qs_step = (HEAVY ? gridDim.z : 1u) * QSEG;
         for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
             const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
-            __syncthreads();  // every wavefront is through with the previous segment (and sQ is complete)
+            __syncthreads();  // every wavefront is through with the previous segment (and with the count prologue's use of the frame area)
+            // the tile's offsets relative to this segment, clamped to it: key w's entries inside the segment are sQ[w] .. sQ[w + 1]
+            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) {
+                const uint32_t o = qoff[k] - q0;   // qoff[TILE_WORDS] is the next tile's first entry (the array has 2^24 + 1 of them)
+                sQ[k] = (qoff_t)(min(max(o, qs), qe) - qs);
+            }
             {
                 const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
                 for (uint32_t i = threadIdx.x; i < qn; i += THREADS) {
@@ -273,19 +274,11 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 if (tvalid) {
                     w = pext12(f2.y >> 13);
                     const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
-                    if (single) {
-                        for (int j = 0; j < nn; j++) {
-                            const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                            const uint32_t a = sQ[w2], b = sQ[w2 + 1];
-                            c += b - a;
-                            nmask |= (b != a ? 1u : 0u) << j;
-                        }
-                    } else {
-                        for (int j = 0; j < nn; j++) {
-                            const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                            const uint32_t a = max((uint32_t)sQ[w2], qs), b = min((uint32_t)sQ[w2 + 1], qe);
-                            if (a < b) { c += b - a; nmask |= 1u << j; }
-                        }
+                    for (int j = 0; j < nn; j++) {
+                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                        const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                        c += b - a;
+                        nmask |= (b != a ? 1u : 0u) << j;
                     }
                 }
                 // inclusive prefix sum over the lanes: DPP (VALU latency), not six trips through the LDS crossbar
@@ -308,8 +301,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                         for (uint32_t m = nmask; m; m &= m - 1u) {
                             const uint32_t j = (uint32_t)__builtin_ctz(m);
                             const uint32_t w2 = j ? (w ^ (1u << (j - 1u))) : w;
-                            const uint32_t a = max((uint32_t)sQ[w2], qs), b = min((uint32_t)sQ[w2 + 1], qe);
-                            const uint32_t cnt = b - a, d0 = (lane << 16) | (a - qs);
+                            const uint32_t a = sQ[w2], cnt = (uint32_t)sQ[w2 + 1] - a, d0 = (lane << 16) | a;
                             if (acc >= rb && acc + cnt <= wend) {
                                 uint32_t *dst = sD + (acc - rb);
                                 dst[0] = d0;

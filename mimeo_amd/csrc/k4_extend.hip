@@ -579,6 +579,26 @@ __global__ void k4_entropy_big_finish(ExtQueues q, int hspthresh, int entropy, m
     }
 }
 
+// ---- shared plus strand: the HSPs of unit u once more, transposed, for its mirror unit ------------------------------------
+// (A, B, +) and (B, A, +) of a self job: every rule of the gap-free stage is symmetric in target and query (seed words
+// and the one-transition rule, N, the x-drop walks, the per-diagonal "already extended" rule — a diagonal keeps its
+// order under the swap —, entropy of the identical columns, HOXD70), so the HSP set of (B, A, +) is the set of (A, B, +)
+// with tstart and qstart exchanged; the pipeline only pairs units when neither scaffold has soft-masked bases (lastz
+// excludes them from TARGET seeding only).  ctr[0] counts the copies.
+__global__ __launch_bounds__(256) void k4_mirror_hsps(mimeo_hsp *__restrict__ hsps, uint32_t *__restrict__ hsp_unit, uint64_t nh,
+                                                      const uint32_t *__restrict__ mirror_dst, unsigned long long *__restrict__ ctr) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t m = mirror_dst[hsp_unit[i]];
+        if (m == NO_MIRROR) continue;
+        const unsigned long long at = nh + wave_slot(ctr);
+        mimeo_hsp h = hsps[i];
+        const uint32_t t = h.tstart;
+        h.tstart = h.qstart; h.qstart = t;
+        hsps[at] = h;
+        hsp_unit[at] = m;
+    }
+}
+
 // ---- host orchestration ---------------------------------------------------------------------
 static uint32_t *g_group_tab = nullptr;  // device copy of the 4-base group table (read-only)
 static std::once_flag g_group_once;
@@ -601,7 +621,7 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
     for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy})
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -626,15 +646,40 @@ uint32_t ext_batch_max_units(uint64_t max_tlen, uint64_t max_qlen) {
     return ubits >= 20 ? (1u << 20) : (1u << ubits);
 }
 
-int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp_out, ExtStats *stats) {
+int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint64_t *nhsp_out, ExtStats *stats,
+                  const std::vector<uint32_t> *mirror_dst) {
     *nhsp_out = 0;
     if (work.empty()) return 0;
-    int rc = start(work, p);
+    int rc = start(work, p, mirror_dst);
     if (rc) return rc;
     return finish(nhsp_out, stats);
 }
 
-int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p) {
+// Device bytes of the batch's queues at the current capacities: followers and walks beyond the frame in eight shards (key +
+// predecessor / hit + unit), long walks, candidates + HSPs (+ their mirror copies), the walk queue of one unit.  The
+// follower sort's second buffer, flags, segment lists and rocPRIM's scratch are sized by the followers actually seen
+// (finish()): up to 41 bytes each on top.
+uint64_t ExtBatch::queue_bytes() const {
+    const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
+    return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : cap_w_ * 8 * 8);
+}
+uint64_t ExtBatch::held_bytes() const {
+    uint64_t b = 0;
+    for (const DeviceBuf *d : {&cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp, &bigseg, &hsps, &hsp_unit})
+        b += d->cap;
+    return b;
+}
+// free device memory plus what the batch's own buffers would give back, less a reserve for chain / gapped scratch
+static int queue_budget(const ExtBatch &b, uint64_t *budget) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t have = (uint64_t)free_b + b.held_bytes(), reserve = std::min<uint64_t>(have / 8, 4ull << 30);
+    *budget = have - reserve;
+    if (getenv("MIMEO_QUEUE_BUDGET_MB")) *budget = (uint64_t)atol(getenv("MIMEO_QUEUE_BUDGET_MB")) << 20;   // tests: force the split
+    return 0;
+}
+
+int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, const std::vector<uint32_t> *mirror_dst) {
     hipStream_t st = stream();
     started_ = false;
     const uint32_t nunits = (uint32_t)work.size();
@@ -657,6 +702,11 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p) {
         if (w.d.same) h_selfs_.push_back(u);
     }
     expect_hits_ = expect_hits;
+    mirror_dst_.clear();
+    if (mirror_dst && std::any_of(mirror_dst->begin(), mirror_dst->end(), [](uint32_t m) { return m != NO_MIRROR; })) {
+        if (mirror_dst->size() != nunits) { set_error("internal: mirror table of the wrong size"); return MIMEO_ERR_ARG; }
+        mirror_dst_ = *mirror_dst;
+    }
     ebits_ = bits_for(max_t + SEED_LEN);
     dbits_ = bits_for(max_t + max_q + SEED_LEN);
     if (ebits_ + dbits_ > 63 || (nunits > 1 && bits_for(nunits - 1) + ebits_ + dbits_ > 64)) {
@@ -686,12 +736,21 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p) {
     // `boost`: the largest excess over these shares that an earlier batch showed (a repeat-rich genome overflows the
     // first batch once, not every batch)
     // (followers and generic-walk hits: capacity PER SHARD, eight shards, with half as much again for their imbalance)
-    cap_f_ = (uint64_t)(expect_hits * 0.02 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    cap_m_ = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    cap_l_ = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    cap_c_ = (uint64_t)(expect_hits * 0.002 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_f_ = (uint64_t)(expect_hits * 0.02 / 8 * 1.5 * boost_f / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_m_ = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost_m / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_l_ = (uint64_t)(expect_hits * 0.002 * boost_l / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_c_ = (uint64_t)(expect_hits * 0.002 * boost_c / shrink) + (uint64_t)(1048576 / shrink) + 64;
     // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
-    cap_w_ = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    cap_w_ = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost_w / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    {   // a batch whose queues cannot fit is cut in two by the caller before anything is allocated (a single unit is tried anyway)
+        uint64_t budget = 0;
+        if ((rc = queue_budget(*this, &budget))) return rc;
+        if (nunits > 1 && queue_bytes() > budget) return MIMEO_ERR_SPLIT;
+    }
+    if (!mirror_dst_.empty()) {
+        if ((rc = mirror.reserve((size_t)nunits * 4 + 16))) return rc;
+        HIP_TRY(hipMemcpyAsync(mirror.p, mirror_dst_.data(), (size_t)nunits * 4, hipMemcpyHostToDevice, st));
+    }
     if (!q_) q_ = new ExtQueues();
     if ((rc = enqueue_heavy())) return rc;
     started_ = true;
@@ -716,9 +775,9 @@ int ExtBatch::enqueue_heavy() {
     {
         if ((rc = fkey.reserve(cap_f * 8 * 8)) || (rc = fprev.reserve(cap_f * 8 * 4)) || (rc = medq.reserve(cap_m * 8 * 8)) ||
             (rc = medu.reserve(cap_m * 8 * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
-            (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp))) ||
-            (rc = hsp_unit.reserve(cap_c * 4)) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8 * 8)))
-            return rc;
+            (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp) * (mirror_dst_.empty() ? 1 : 2))) ||
+            (rc = hsp_unit.reserve(cap_c * 4 * (mirror_dst_.empty() ? 1 : 2))) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8 * 8)))
+            return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
         q.ctr = (ExtCounters *)ctr.p;
         q.cand = (Cand *)cand.p; q.fkey = (uint64_t *)fkey.p; q.fprev = (uint32_t *)fprev.p;
         q.medq = (uint2 *)medq.p; q.medu = (uint32_t *)medu.p; q.longq = (uint2 *)longq.p; q.longu = (uint32_t *)longu.p;
@@ -832,7 +891,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         if (!over && nf) {
             if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
                 (rc = segs.reserve(nf * 8)) || (rc = bigseg.reserve(nf * 8)))
-                return rc;
+                return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
             size_t t1 = 0, t2 = 0;
             // the eight shards gathered into fkey2 / fprev2; the sort writes back into the (now free) shard area
             hipLaunchKernelGGL(k4_compact_followers, dim3(1024), dim3(256), 0, st, q, (uint64_t *)fkey2.p, (uint32_t *)fprev2.p);
@@ -840,7 +899,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
                                               (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             rocprim::counting_iterator<uint64_t> iota(0);
             HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)flags.p, (uint64_t *)segs.p, (uint64_t *)nsel.p, (size_t)nf, st));
-            if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc;
+            if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
             HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
                                               (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st, (const uint64_t *)fkey.p,
@@ -897,16 +956,39 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         cap_c = std::max<uint64_t>(cap_c, 2 * c.ncand + 65536);
         cap_w = std::max<uint64_t>(cap_w, c.nwalk_over + c.nwalk_over / 4 + 1024);
         if (stats) stats->reruns++;
+        // what this batch showed goes into the sizing of the next ones whatever happens to it now
+        if (expect_hits > 1e6) {
+            boost_f = std::min(4096.0, std::max(boost_f, 1.5 * (double)(8 * maxf) / (0.02 * expect_hits)));
+            boost_m = std::min(4096.0, std::max(boost_m, 1.5 * (double)(8 * maxm) / (0.03 * expect_hits)));
+        }
+        {
+            uint64_t budget = 0;
+            if ((rc = queue_budget(*this, &budget))) return rc;
+            if (nunits > 1 && queue_bytes() > budget) return MIMEO_ERR_SPLIT;   // the caller cuts the batch in two
+        }
         if ((rc = enqueue_heavy())) return rc;   // the batch again, on this stream, with room
+    }
+    uint64_t nhsp = c.nhsp;
+    if (!mirror_dst_.empty() && nhsp) {   // shared plus strand: the mirror units receive their (transposed) HSPs
+        unsigned long long *mctr = (unsigned long long *)((char *)mirror.p + (size_t)nunits * 4 + (8 - ((size_t)nunits * 4) % 8) % 8);
+        HIP_TRY(hipMemsetAsync(mctr, 0, 8, st));
+        hipLaunchKernelGGL(k4_mirror_hsps, dim3((uint32_t)std::min<uint64_t>(1024, (nhsp + 255) / 256)), dim3(256), 0, st, (mimeo_hsp *)hsps.p,
+                           (uint32_t *)hsp_unit.p, nhsp, (const uint32_t *)mirror.p, mctr);
+        unsigned long long added = 0;
+        HIP_TRY(hipMemcpyAsync(&added, mctr, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        nhsp += added;
     }
     h_unit_hits.resize(nunits);
     HIP_TRY(hipMemcpy(h_unit_hits.data(), unit_hits.p, (size_t)nunits * 8, hipMemcpyDeviceToHost));
-    *nhsp_out = c.nhsp;
+    *nhsp_out = nhsp;
     if (expect_hits > 1e6) {
         const double e = expect_hits;
-        const double r = std::max({(double)nf_total / (0.02 * e), (double)nm_total / (0.03 * e), (double)c.nlong / (0.002 * e),
-                                   (double)c.ncand / (0.002 * e), (double)c.nwalk_total / (0.12 * e)});
-        boost = std::min(64.0, std::max(boost, 1.5 * r));
+        boost_f = std::min(4096.0, std::max(boost_f, 1.5 * (double)nf_total / (0.02 * e)));
+        boost_m = std::min(4096.0, std::max(boost_m, 1.5 * (double)nm_total / (0.03 * e)));
+        boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * e)));
+        boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * e)));
+        boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * e)));
     }
     if (stats) {
         for (uint32_t u = 0; u < nunits; u++) {

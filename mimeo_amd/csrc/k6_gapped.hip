@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict
     uint32_t lo = 0, hi = 0;
     if (Y >= O + E) hi = min(lenB, (uint32_t)((Y - O) / E));
     const uint32_t ext = (uint32_t)((Y + 200) / E) + 2u;  // how far an insertion can carry a live cell to the right
-    bool overflow = hi + ext + 2u >= ANY_COLS;
+    bool overflow = min(lenB, hi + ext) + 2u >= ANY_COLS;   // no row can hold more live columns than the query has left
     {
         AnyRow r0 = any_row(base, 0);
         for (uint32_t j = tid; j <= hi && !overflow; j += ANY_THREADS) {

@@ -239,6 +239,30 @@ int regroup_hsps_device(mimeo_hsp *d_hsps, uint32_t *d_hunit, uint64_t nh, const
     return 0;
 }
 
+// (target scaffold, query scaffold) of every group whose gapped extension hit a limit (a few at most)
+__global__ void k_overflowed_groups(const Group *__restrict__ groups, uint32_t ngroups, uint2 *__restrict__ out, unsigned int *__restrict__ n, uint32_t cap) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ngroups && groups[g].overflow) {
+        const unsigned int i = atomicAdd(n, 1u);
+        if (i < cap) out[i] = make_uint2(groups[g].tid, groups[g].qid);
+    }
+}
+int overflowed_groups_device(const Group *d_groups, uint32_t ngroups, uint64_t expect, std::vector<uint2> *out) {
+    hipStream_t st = stream();
+    int rc;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(expect, 1u << 20);
+    if ((rc = g_tmp.reserve((size_t)cap * 8 + 16))) return rc;
+    unsigned int *n = (unsigned int *)((char *)g_tmp.p + (size_t)cap * 8);
+    HIP_TRY(hipMemsetAsync(n, 0, 4, st));
+    hipLaunchKernelGGL(k_overflowed_groups, dim3((ngroups + 255) / 256), dim3(256), 0, st, d_groups, ngroups, (uint2 *)g_tmp.p, n, cap);
+    unsigned int got = 0;
+    HIP_TRY(hipMemcpyAsync(&got, n, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out->resize(std::min<uint32_t>(got, cap));
+    if (!out->empty()) HIP_TRY(hipMemcpy(out->data(), g_tmp.p, out->size() * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int group_summary_device(const Group *d_groups, uint32_t ngroups, uint64_t out[3]) {
     hipStream_t st = stream();
     int rc;

@@ -79,6 +79,7 @@ struct IndexCache {
     }
     // end of a call: indexes go to their genome when it keeps them (also after an error: they are
     // complete), else back to the pool
+    ~IndexCache() { clear(); }   // error paths that leave the call early give the indexes back too
     void clear() {
         for (auto &kv : m) {
             if (adopted.count(kv.first)) continue;  // still owned by the genome
@@ -90,22 +91,45 @@ struct IndexCache {
     }
 };
 
-static ExtBatch g_ext, g_ext2;   // two: the heavy phase of a batch is enqueued while the batch before it is finished
-static hipStream_t g_tail_stream = nullptr;   // tails, chain and gapped extension of a batch, beside the next batch's heavy phase
+static ExtBatch g_ext;
 static DeviceBuf g_scratch, g_aln, g_dense, g_groups;
 // tables of the packed path (run_packed)
 static DeviceBuf d_toff, d_tstart, d_tlen, d_trank, d_qoff, d_qstart, d_qlen, d_qrank, d_pairidx, d_pt, d_pq, d_tview, d_qvf, d_qvr, d_utab;
+static std::vector<std::pair<uint64_t, int>> g_failed;   // pairs of the last call that hit a limit
+const std::vector<std::pair<uint64_t, int>> &failed_pairs() { return g_failed; }
 
+constexpr uint64_t NO_PAIR = ~0ull;
 struct Unit {
-    uint64_t pair;  // index into pair_t / pair_q
+    uint64_t pair;          // index into pair_t / pair_q
     uint32_t tid, qid, minus;
+    uint64_t mirror_pair;   // plus-strand unit of a self job: the pair (qid, tid) that receives the transposed HSPs, or NO_PAIR
+};
+
+// switches read once per call (tests change them between calls)
+struct Switches {
+    bool pack, mirror, no_diag0, timing, k6_stats;
+    uint64_t pack_member, pack_super, index_budget_mb;
+    size_t pack_min, batch_units;
+    double batch_hits;
+    static const char *env(const char *k) { return getenv(k); }
+    Switches() {
+        pack = !(env("MIMEO_PACK") && !atoi(env("MIMEO_PACK")));
+        mirror = !(env("MIMEO_MIRROR") && !atoi(env("MIMEO_MIRROR")));
+        no_diag0 = env("MIMEO_NO_DIAG0") != nullptr;
+        timing = env("MIMEO_TIMING") != nullptr;
+        k6_stats = env("MIMEO_K6_STATS") != nullptr;
+        pack_member = env("MIMEO_PACK_MEMBER") ? (uint64_t)atol(env("MIMEO_PACK_MEMBER")) : (6ull << 20);
+        pack_super = env("MIMEO_PACK_SUPER") ? (uint64_t)atol(env("MIMEO_PACK_SUPER")) : (20ull << 20);
+        pack_min = env("MIMEO_PACK_MIN") ? (size_t)atol(env("MIMEO_PACK_MIN")) : 8;
+        index_budget_mb = env("MIMEO_INDEX_BUDGET_MB") ? (uint64_t)atol(env("MIMEO_INDEX_BUDGET_MB")) : 0;
+        batch_units = env("MIMEO_BATCH_UNITS") ? (size_t)std::max(1l, atol(env("MIMEO_BATCH_UNITS"))) : 0;
+        batch_hits = env("MIMEO_BATCH_HITS") ? atof(env("MIMEO_BATCH_HITS")) : 2.5e10;
+    }
 };
 
 // mimeo_shutdown: give the work buffers and streams back
 void release_pipeline_buffers() {
     g_ext.release();
-    g_ext2.release();
-    if (g_tail_stream) { (void)hipStreamDestroy(g_tail_stream); g_tail_stream = nullptr; }
     g_scratch.release();
     g_aln.release();
     g_dense.release();
@@ -145,29 +169,43 @@ static int upload(DeviceBuf &b, const std::vector<T> &v) {
     return 0;
 }
 
+static void record_failure(uint64_t pair, uint32_t tid, uint32_t qid, char strand, std::vector<char> &failed) {
+    if (failed[pair]) return;
+    failed[pair] = 1;
+    g_failed.emplace_back(pair, MIMEO_ERR_LIMIT);
+    char msg[256];
+    snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns, or score beyond "
+             "int32: not supported; the pair is left out (mimeo_get_failed_pairs)", tid, qid, strand);
+    set_error(msg);   // readable through mimeo_last_error() although the call succeeds
+}
+
 static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint32_t *pair_t, const uint32_t *pair_q, uint64_t npairs,
-                      const mimeo_params *p, std::vector<std::vector<mimeo_alignment>> &per_pair, ExtStats &est, float &ms_chain,
-                      float &ms_gapped, float &ms_index, bool *used) {
+                      const mimeo_params *p, const Switches &sw, std::vector<std::vector<mimeo_alignment>> &per_pair, std::vector<char> &failed,
+                      ExtStats &est, float &ms_chain, float &ms_gapped, float &ms_index, bool *used) {
     *used = false;
-    if (getenv("MIMEO_PACK") && !atoi(getenv("MIMEO_PACK"))) return 0;
+    if (!sw.pack) return 0;
     if (npairs == 0 || npairs >= (1ull << 30)) return 0;
     // K34 works a 10 Mbp x 10 Mbp unit off at 13.5 ps per seed hit, a 5 Mbp x 5 Mbp one at 21.7, a 2 Mbp x 2 Mbp one at 117 (4096
     // tiles to stage whatever the scaffold size): scaffolds of up to 6 Mbp are packed into super-scaffolds of about 20 Mbp
     // when there are at least eight of them (C2, ten scaffolds of 5 Mbp: 144 -> 106 ms per job).
-    const uint64_t member_max = getenv("MIMEO_PACK_MEMBER") ? (uint64_t)atol(getenv("MIMEO_PACK_MEMBER")) : (6ull << 20);
-    const uint64_t super_len = getenv("MIMEO_PACK_SUPER") ? (uint64_t)atol(getenv("MIMEO_PACK_SUPER")) : (20ull << 20);
-    const size_t pack_min = getenv("MIMEO_PACK_MIN") ? (size_t)atol(getenv("MIMEO_PACK_MIN")) : 8;
+    const uint64_t member_max = sw.pack_member, super_len = sw.pack_super;
+    const size_t pack_min = sw.pack_min;
     // indexes kept on a genome handle say that the caller issues the job as many calls (a row per call): they are used
     if (A->keep_indexes || QG->keep_indexes) return 0;
+    {   // the cheap rejections first: too few small scaffolds among the ones named (before any |T| x |Q| table is made)
+        std::vector<uint8_t> seen_t(A->scaf.size(), 0), seen_q(QG->scaf.size(), 0);
+        size_t small_t = 0, small_q = 0;
+        for (uint64_t k = 0; k < npairs; k++) {
+            if (!seen_t[pair_t[k]]) { seen_t[pair_t[k]] = 1; small_t += A->scaf[pair_t[k]].len <= member_max; }
+            if (!seen_q[pair_q[k]]) { seen_q[pair_q[k]] = 1; small_q += QG->scaf[pair_q[k]].len <= member_max; }
+        }
+        if (std::max(small_t, small_q) < pack_min) return 0;
+    }
     host_plan::CrossProduct cp = host_plan::cross_product(pair_t, pair_q, npairs, A->scaf.size(), QG->scaf.size());
     const std::vector<uint32_t> &tset = cp.tset, &qset = cp.qset, &trank = cp.trank, &qrank = cp.qrank, &pairidx = cp.pairidx;
     const std::vector<std::pair<uint64_t, uint64_t>> &dups = cp.dups;   // (duplicate, first occurrence): answered from the first
     const size_t nq = qset.size(), distinct = cp.distinct;
     if (!cp.full) return 0;   // not the full cross product T x Q
-    size_t small_t = 0, small_q = 0;
-    for (uint32_t t : tset) small_t += A->scaf[t].len <= member_max;
-    for (uint32_t q : qset) small_q += QG->scaf[q].len <= member_max;
-    if (std::max(small_t, small_q) < pack_min) return 0;
     // one genome, the same scaffolds in both roles: the two roles share the super-scaffolds, and the main diagonals stay
     // with k4_diag0.  A subset of the targets against all scaffolds (a rank's share of a self job, dist.py) packs the two
     // roles separately: a scaffold's main diagonal is then an ordinary diagonal of its unit, whose seed hits are resolved
@@ -189,7 +227,7 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         uint64_t budget = (uint64_t)(0.6 * (double)free_b);
-        if (getenv("MIMEO_INDEX_BUDGET_MB")) budget = (uint64_t)atol(getenv("MIMEO_INDEX_BUDGET_MB")) << 20;
+        if (sw.index_budget_mb) budget = sw.index_budget_mb << 20;
         if (need > budget) return 0;
     }
     *used = true;
@@ -226,14 +264,26 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     R.pair_t = (const uint32_t *)d_pt.p; R.pair_q = (const uint32_t *)d_pq.p;
     R.t_view = (const StrandView *)d_tview.p; R.q_view_fwd = (const StrandView *)d_qvf.p; R.q_view_rc = (const StrandView *)d_qvr.p;
 
-    // ---- units: (target super, query super, strand), target-major
-    struct SUnit { uint32_t ts, qs, minus; };
+    // ---- units: (target super, query super, strand), target-major.  Self job: the plus-strand unit (S1, S2) with S1 < S2 also
+    // serves (S2, S1) — its HSPs transposed — when neither super holds soft-masked bases (shared plus strand, k4_mirror_hsps)
+    struct SUnit { uint32_t ts, qs, minus, mirrored; };
     std::vector<SUnit> units;
     uint64_t max_t = 1, max_q = 1;
+    const bool plus = (p->strand & MIMEO_STRAND_PLUS) != 0;
+    auto can_mirror = [&](uint32_t a, uint32_t b) {
+        return self && sw.mirror && plus && a != b && !ST.supers[a].fwd.sv_target && !ST.supers[b].fwd.sv_target;
+    };
     for (uint32_t ts = 0; ts < ST.supers.size(); ts++)
         for (uint32_t qs = 0; qs < SQ.supers.size(); qs++)
-            for (uint32_t minus = 0; minus < 2; minus++)
-                if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS)) units.push_back(SUnit{ts, qs, minus});
+            for (uint32_t minus = 0; minus < 2; minus++) {
+                if (!(p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))) continue;
+                if (!minus && can_mirror(ts, qs)) {
+                    if (ts > qs) continue;   // served by (qs, ts, +)
+                    units.push_back(SUnit{ts, qs, 0, 1});
+                } else {
+                    units.push_back(SUnit{ts, qs, minus, 0});
+                }
+            }
     for (auto &s : ST.supers) max_t = std::max<uint64_t>(max_t, s.len);
     for (auto &s : SQ.supers) max_q = std::max<uint64_t>(max_q, s.len);
     IndexCache cache;
@@ -246,32 +296,53 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     }
     rc = cache.build_all();
     size_t max_units = std::min<size_t>(8192, ext_batch_max_units(max_t, max_q));
-    if (getenv("MIMEO_BATCH_UNITS")) max_units = std::max<size_t>(1, std::min<size_t>(max_units, (size_t)atol(getenv("MIMEO_BATCH_UNITS"))));
-    const double max_hits = getenv("MIMEO_BATCH_HITS") ? atof(getenv("MIMEO_BATCH_HITS")) : 2.5e10;
+    if (sw.batch_units) max_units = std::min<size_t>(max_units, sw.batch_units);
+    double max_hits = sw.batch_hits;
     const uint64_t max_groups = 1ull << 22;   // K5 names a group in 23 bits
     for (size_t b0 = 0; b0 < units.size() && !rc;) {
         std::vector<UnitWork> work;
         std::vector<uint3> utab;
+        std::vector<uint32_t> mirror_dst;
         double hits = 0;
         uint64_t tmembers = 0;
-        uint32_t last_ts = 0xFFFFFFFFu;
         size_t b1 = b0;
-        for (; b1 < units.size() && work.size() < max_units; b1++) {
+        for (; b1 < units.size(); b1++) {
             const SUnit &u = units[b1];
+            if (work.size() + (u.mirrored ? 2 : 1) > max_units && !work.empty()) break;
             UnitWork w;
             memset(&w, 0, sizeof w);
             if ((rc = cache.get(ST.supers[u.ts], 0, true, &w.ti, &w.d.T)) || (rc = cache.get(SQ.supers[u.qs], (int)u.minus, false, &w.qi, &w.d.Q))) break;
             const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
-            const uint64_t tm_new = tmembers + (u.ts != last_ts ? ST.members[u.ts].size() : 0);
+            // groups of the batch: at most (target members named) x nq x 2 (an upper bound; a mirror unit names the other super's)
+            const uint64_t tm_new = tmembers + ST.members[u.ts].size() + (u.mirrored ? ST.members[u.qs].size() : 0);
             if (!work.empty() && (hits + e > max_hits || tm_new * nq * 2 > max_groups)) break;
-            hits += e; tmembers = tm_new; last_ts = u.ts;
-            w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1u : 0u;
+            hits += e; tmembers = tm_new;
+            w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !sw.no_diag0) ? 1u : 0u;
             work.push_back(w);
             utab.push_back(make_uint3(u.ts, u.qs, u.minus));
+            mirror_dst.push_back(NO_MIRROR);
+            if (u.mirrored) {   // (qs, ts, +): no indexes, no heavy phase; receives the transposed HSPs
+                UnitWork m;
+                memset(&m, 0, sizeof m);
+                StrandView sv;
+                IndexCache::key_of(ST.supers[u.qs], 0, true, &sv); m.d.T = sv;
+                IndexCache::key_of(ST.supers[u.ts], 0, false, &sv); m.d.Q = sv;
+                mirror_dst.back() = (uint32_t)work.size();
+                work.push_back(m);
+                utab.push_back(make_uint3(u.qs, u.ts, 0));
+                mirror_dst.push_back(NO_MIRROR);
+            }
         }
         if (rc) break;
         uint64_t nh = 0;
-        if ((rc = g_ext.run(work, p, &nh, &est))) break;
+        rc = g_ext.run(work, p, &nh, &est, &mirror_dst);
+        if (rc == MIMEO_ERR_SPLIT) {   // the queues of this batch do not fit: smaller batches from here on
+            rc = 0;
+            max_hits = std::max(1.0, hits / 2);
+            if (b1 - b0 > 1) max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
+            continue;
+        }
+        if (rc) break;
         g_stats.super_units += work.size();
         g_stats.hsps += nh;
         for (size_t i = b0; i < b1; i++) g_stats.query_bases_scanned += SQ.supers[units[i].qs].len;
@@ -292,15 +363,10 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
             if ((rc = group_summary_device((const Group *)g_groups.p, ngroups, sum))) break;
             Group last;
             HIP_TRY(hipMemcpy(&last, (const Group *)g_groups.p + (ngroups - 1), sizeof(Group), hipMemcpyDeviceToHost));
-            if (sum[1]) {
-                Group bad;
-                HIP_TRY(hipMemcpy(&bad, (const Group *)g_groups.p + (sum[2] - 1), sizeof(Group), hipMemcpyDeviceToHost));
-                char msg[256];
-                snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns, or "
-                         "score beyond int32: not supported", bad.tid, bad.qid, bad.minus ? '-' : '+');
-                set_error(msg);
-                rc = MIMEO_ERR_LIMIT;
-                break;
+            if (sum[1]) {   // a pair that hit a limit is left out; the others go on (the reference's script has no `set -e`: utils.py:125-128)
+                std::vector<uint2> bad;
+                if ((rc = overflowed_groups_device((const Group *)g_groups.p, ngroups, sum[1], &bad))) break;
+                for (const uint2 &tq : bad) record_failure(pairidx[(size_t)trank[tq.x] * nq + qrank[tq.y]], tq.x, tq.y, '?', failed);
             }
             g_stats.chained_hsps += sum[0];
             const uint64_t naln_total = (uint64_t)last.job0 + last.naln;
@@ -316,38 +382,79 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     g_stats.index_blocks++;
     g_stats.pair_strands += distinct * (((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH) ? 2 : 1);
     if (!rc)
-        for (auto &d : dups) per_pair[d.first] = per_pair[d.second];
+        for (auto &d : dups) { per_pair[d.first] = per_pair[d.second]; if (failed[d.second]) failed[d.first] = 1; }
     return rc;
 }
 
-int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q,
+int align_units_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_t *pair_t, const uint32_t *pair_q, const uint8_t *pair_strand,
                      uint64_t npairs, const mimeo_params *p, mimeo_alignment **out, uint64_t *nout) {
     auto t0 = std::chrono::steady_clock::now();
     memset(&g_stats, 0, sizeof g_stats);
+    g_failed.clear();
+    const Switches sw;
     const mimeo_genome *QG = B ? B : A;
     uint64_t max_t = 1, max_q = 1;
+    bool uniform = true;   // every pair on the same strands: what run_jobs.sh asks for (wrappers.py:1031 --strand=both)
+    const uint32_t all = (uint32_t)p->strand & MIMEO_STRAND_BOTH;
+    auto strands_of = [&](uint64_t k) { return pair_strand ? ((uint32_t)pair_strand[k] & all) : all; };
     for (uint64_t k = 0; k < npairs; k++) {
         if (pair_t[k] >= A->scaf.size() || pair_q[k] >= QG->scaf.size()) { set_error("pair index out of range"); return MIMEO_ERR_ARG; }
         max_t = std::max(max_t, A->scaf[pair_t[k]].len);
         max_q = std::max(max_q, QG->scaf[pair_q[k]].len);
+        if (strands_of(k) != strands_of(0)) uniform = false;
     }
-    // units in target-major order (stable in the caller's pair order): neighbouring units share the target index
-    std::vector<uint64_t> ord(npairs);
-    for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
-    std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) { return pair_t[a] < pair_t[b]; });
-    std::vector<Unit> units;
-    for (uint64_t k = 0; k < npairs; k++)
-        for (uint32_t minus = 0; minus < 2; minus++)
-            if (p->strand & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))
-                units.push_back(Unit{ord[k], pair_t[ord[k]], pair_q[ord[k]], minus});
     std::vector<std::vector<mimeo_alignment>> per_pair(npairs);
+    std::vector<char> failed(npairs, 0);
     float ms_chain = 0, ms_gapped = 0, ms_index = 0;
     ExtStats est;
     int rc = 0;
     bool packed = false;
     HIP_TRY(hipStreamSynchronize(stream()));
-    if ((rc = run_packed(A, QG, pair_t, pair_q, npairs, p, per_pair, est, ms_chain, ms_gapped, ms_index, &packed))) return rc;
+    if (uniform && npairs) {
+        mimeo_params pp = *p;
+        pp.strand = (int32_t)strands_of(0);
+        if (pp.strand && (rc = run_packed(A, QG, pair_t, pair_q, npairs, &pp, sw, per_pair, failed, est, ms_chain, ms_gapped, ms_index, &packed))) return rc;
+    }
     if (!packed) {
+    // units in target-major order (stable in the caller's pair order): neighbouring units share the target index
+    std::vector<uint64_t> ord(npairs);
+    for (uint64_t k = 0; k < npairs; k++) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) { return pair_t[a] < pair_t[b]; });
+    // Shared plus strand (self jobs): when the list names (t, q) and (q, t), t != q, both on the plus strand, and neither
+    // scaffold has soft-masked bases, the unit of the pair with t < q also produces the HSPs of the other one, transposed
+    // (k4_mirror_hsps): one seed scan and one gap-free stage instead of two.  Chain and gapped extension run per pair as
+    // ever (their tie-breaks are not symmetric).  First occurrences only; MIMEO_MIRROR=0 switches it off (tests).
+    std::vector<uint64_t> mirror_of(npairs, NO_PAIR);   // canonical pair -> the pair it also serves
+    std::vector<char> served(npairs, 0);                // pairs whose plus strand comes from their partner
+    if (A == QG && sw.mirror && (all & MIMEO_STRAND_PLUS)) {
+        struct E { uint64_t key, k; };
+        std::vector<E> es;
+        for (uint64_t k = 0; k < npairs; k++) {
+            const uint32_t t = pair_t[k], q = pair_q[k];
+            if (t == q || !(strands_of(k) & MIMEO_STRAND_PLUS)) continue;
+            if (A->scaf[t].fwd.sv_target || A->scaf[q].fwd.sv_target) continue;   // soft-masked bases: target-only seeding rule
+            es.push_back(E{((uint64_t)std::min(t, q) << 32) | std::max(t, q), k});
+        }
+        std::sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.key != b.key ? a.key < b.key : a.k < b.k; });
+        for (size_t i = 0; i < es.size();) {
+            size_t j = i;
+            uint64_t lo = NO_PAIR, hi = NO_PAIR;   // first occurrence of (min, max) and of (max, min)
+            for (; j < es.size() && es[j].key == es[i].key; j++) {
+                const uint64_t k = es[j].k;
+                if (pair_t[k] < pair_q[k]) { if (lo == NO_PAIR) lo = k; } else if (hi == NO_PAIR) hi = k;
+            }
+            if (lo != NO_PAIR && hi != NO_PAIR) { mirror_of[lo] = hi; served[hi] = 1; }
+            i = j;
+        }
+    }
+    std::vector<Unit> units;
+    for (uint64_t k = 0; k < npairs; k++)
+        for (uint32_t minus = 0; minus < 2; minus++) {
+            const uint64_t pk = ord[k];
+            if (!(strands_of(pk) & (minus ? MIMEO_STRAND_MINUS : MIMEO_STRAND_PLUS))) continue;
+            if (!minus && served[pk]) continue;
+            units.push_back(Unit{pk, pair_t[pk], pair_q[pk], minus, minus ? NO_PAIR : mirror_of[pk]});
+        }
     // Seed indexes cost 64 MiB + 52 bytes per base and strand, so a large or fragmented genome cannot keep them all
     // (a 1 Gbp genome, both strands: 117 GB; 2000 small scaffolds x 2 strands: 256 GB of offset arrays).  When the
     // indexes a call needs exceed the budget (60 % of the free device memory; MIMEO_INDEX_BUDGET_MB for tests) the
@@ -362,7 +469,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             StrandView sv;
             if (!A->kept.count(IndexCache::kept_key(A, IndexCache::key_of(ts, 0, true, &sv)))) tb[u.tid] = seed_index_bytes(ts.len);
             if (!QG->kept.count(IndexCache::kept_key(QG, IndexCache::key_of(qs, (int)u.minus, false, &sv))))
-                qb[u.qid] = std::max<uint64_t>(qb[u.qid], seed_index_bytes(qs.len) * ((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH ? 2 : 1));
+                qb[u.qid] = std::max<uint64_t>(qb[u.qid], seed_index_bytes(qs.len) * (all == MIMEO_STRAND_BOTH ? 2 : 1));
         }
         uint64_t need = 0, tmax = 1, qmax = 1;
         for (auto &kv : tb) { need += kv.second; tmax = std::max(tmax, kv.second); }
@@ -370,7 +477,7 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         uint64_t budget = (uint64_t)(0.6 * (double)free_b);
-        if (getenv("MIMEO_INDEX_BUDGET_MB")) budget = (uint64_t)atol(getenv("MIMEO_INDEX_BUDGET_MB")) << 20;
+        if (sw.index_budget_mb) budget = sw.index_budget_mb << 20;
         if (need > budget && !units.empty()) {
             const uint64_t Bt = std::max<uint64_t>(1, budget / 2 / tmax), Bq = std::max<uint64_t>(1, budget / 2 / qmax);
             std::map<uint32_t, uint64_t> trank, qrank;
@@ -394,10 +501,12 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     }
     // batch limits: the follower key names at most 2^(64 - end bits - diagonal bits) units; K5/K6 take at most
     // MAX_GROUPS groups; and the queues of a batch are sized from its expected seed hits (2.5e10: a C4 row is 1.6e10)
+    // — less when the free device memory says so (ExtBatch answers MIMEO_ERR_SPLIT: repeat-rich input beside resident
+    // indexes, C5: half of all hits are followers inside microsatellites)
     const size_t MAX_GROUPS = 8192;
     size_t max_units = std::min<size_t>(MAX_GROUPS, ext_batch_max_units(max_t, max_q));
-    if (getenv("MIMEO_BATCH_UNITS")) max_units = std::max<size_t>(1, std::min<size_t>(max_units, (size_t)atol(getenv("MIMEO_BATCH_UNITS"))));
-    const double max_hits = getenv("MIMEO_BATCH_HITS") ? atof(getenv("MIMEO_BATCH_HITS")) : 2.5e10;
+    if (sw.batch_units) max_units = std::min<size_t>(max_units, sw.batch_units);
+    double max_hits = sw.batch_hits;
     hipStream_t st = stream();
     HIP_TRY(hipStreamSynchronize(st));
     size_t blk_begin = 0;
@@ -413,138 +522,121 @@ int align_pairs_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             }
         }
         rc = cache.build_all();
-        // ---- the batches of this block
-        struct BatchPlan { size_t b0, b1; std::vector<UnitWork> work; std::vector<Group> groups; };
-        std::vector<BatchPlan> plan;
-        // MIMEO_OVERLAP=1 (measured, not the default): a block of 32 units or more is cut into at least four batches and a
-        // batch's tails, chain and gapped extension run on a second stream beside the heavy phase of the next batch (two
-        // sets of queues).  On a C4 row every stage stretches by what it overlaps — K34 215 -> 266 ms, gapped 44 -> 102 —
-        // and the row takes 356 ms instead of 344: the stages are throughput-bound on the same SIMDs, there is no idle
-        // resource to fill.  Kept for the record and for the identity test.
-        const bool overlap_ok = getenv("MIMEO_OVERLAP") && atoi(getenv("MIMEO_OVERLAP")) && !getenv("MIMEO_BATCH_UNITS");
-        size_t cut_units = max_units;
-        if (overlap_ok && blk_end - blk_begin >= 32) cut_units = std::min<size_t>(max_units, (blk_end - blk_begin + 3) / 4);
+        // ---- the batches of this block, one at a time
         for (size_t b0 = blk_begin; b0 < blk_end && !rc;) {
-            BatchPlan bp;
+            std::vector<UnitWork> work;
+            std::vector<Group> groups;
+            std::vector<uint64_t> pair_of;      // pair of every work unit (a mirror unit's is the served pair)
+            std::vector<uint32_t> mirror_dst;
             double hits = 0;
             size_t b1 = b0;
-            for (; b1 < blk_end && bp.work.size() < cut_units; b1++) {
+            for (; b1 < blk_end; b1++) {
                 const Unit &u = units[b1];
+                const bool mir = u.mirror_pair != NO_PAIR;
+                if (!work.empty() && work.size() + (mir ? 2 : 1) > max_units) break;
                 const Scaffold &ts = A->scaf[u.tid], &qs = QG->scaf[u.qid];
                 UnitWork w;
                 memset(&w, 0, sizeof w);
                 if ((rc = cache.get(ts, 0, true, &w.ti, &w.d.T)) || (rc = cache.get(qs, (int)u.minus, false, &w.qi, &w.d.Q))) break;
                 const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
-                if (!bp.work.empty() && hits + e > max_hits) break;
+                if (!work.empty() && hits + e > max_hits) break;
                 hits += e;
-                w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !getenv("MIMEO_NO_DIAG0")) ? 1u : 0u;
-                bp.work.push_back(w);
+                w.d.same = (w.d.T.pw == w.d.Q.pw && w.d.T.len == w.d.Q.len && !sw.no_diag0) ? 1u : 0u;
                 Group g;
                 memset(&g, 0, sizeof g);
                 g.T = w.d.T; g.Q = w.d.Q; g.tid = u.tid; g.qid = u.qid; g.minus = u.minus;
-                bp.groups.push_back(g);
+                work.push_back(w); groups.push_back(g); pair_of.push_back(u.pair); mirror_dst.push_back(NO_MIRROR);
+                if (mir) {   // (qid, tid, +): no indexes, no heavy phase; receives the transposed HSPs
+                    UnitWork m;
+                    memset(&m, 0, sizeof m);
+                    IndexCache::key_of(qs, 0, true, &m.d.T);    // no soft-masked bases on either: the plain planes in both roles
+                    IndexCache::key_of(ts, 0, false, &m.d.Q);
+                    Group gm;
+                    memset(&gm, 0, sizeof gm);
+                    gm.T = m.d.T; gm.Q = m.d.Q; gm.tid = u.qid; gm.qid = u.tid; gm.minus = 0;
+                    mirror_dst.back() = (uint32_t)work.size();
+                    work.push_back(m); groups.push_back(gm); pair_of.push_back(u.mirror_pair); mirror_dst.push_back(NO_MIRROR);
+                }
             }
             if (rc) break;
-            bp.b0 = b0; bp.b1 = b1;
-            plan.push_back(std::move(bp));
-            b0 = b1;
-        }
-        ExtBatch *ext[2] = {&g_ext, &g_ext2};
-        const bool overlap = !rc && plan.size() > 1 && overlap_ok;
-        hipStream_t s_tail = st;
-        if (overlap) {
-            if (!g_tail_stream) {
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = the numerically lowest = highest priority
-                if (hipStreamCreateWithPriority(&g_tail_stream, hipStreamNonBlocking, hi) != hipSuccess) { set_error("hipStreamCreateWithPriority failed"); rc = MIMEO_ERR_HIP; }
-            }
-            s_tail = g_tail_stream;
-        }
-        static const bool timing = getenv("MIMEO_TIMING") != nullptr;   // development: host wall time of the phases of a batch
-        if (!rc && !plan.empty()) rc = ext[0]->start(plan[0].work, p);
-        for (size_t k = 0; k < plan.size() && !rc; k++) {
-            BatchPlan &bp = plan[k];
-            std::vector<Group> &groups = bp.groups;
-            const size_t b0 = bp.b0, b1 = bp.b1;
             auto tb0 = std::chrono::steady_clock::now();
-            if (!overlap && k) {
-                if ((rc = ext[0]->start(bp.work, p))) break;
-            } else if (overlap && k + 1 < plan.size()) {   // the next batch's heavy phase is in the queue before this one's tails are waited for
-                set_thread_stream(st);
-                if ((rc = ext[(k + 1) & 1]->start(plan[k + 1].work, p))) break;
-            }
-            set_thread_stream(s_tail);
-            hipStream_t sk = stream();
-            ExtBatch &X = *ext[overlap ? (k & 1) : 0];
             uint64_t nh = 0;
-            if ((rc = X.finish(&nh, &est))) break;
+            rc = g_ext.run(work, p, &nh, &est, &mirror_dst);
+            if (rc == MIMEO_ERR_SPLIT) {   // the queues of this batch do not fit beside the indexes: smaller batches from here on
+                rc = 0;
+                max_hits = std::max(1.0, hits / 2);
+                if (b1 - b0 > 1) max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
+                continue;
+            }
+            if (rc) break;
             auto tb1 = std::chrono::steady_clock::now();
-            g_stats.pair_strands += bp.work.size();
+            g_stats.pair_strands += work.size();
             g_stats.hsps += nh;
             for (size_t i = b0; i < b1; i++) g_stats.query_bases_scanned += QG->scaf[units[i].qid].len;
             g_stats.batches++;
             if (nh) {
                 if ((rc = g_groups.reserve(groups.size() * sizeof(Group))) || (rc = g_aln.reserve(nh * sizeof(mimeo_alignment)))) break;
-                if (hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, sk) != hipSuccess) {
+                if (hipMemcpyAsync(g_groups.p, groups.data(), groups.size() * sizeof(Group), hipMemcpyHostToDevice, st) != hipSuccess) {
                     set_error("hipMemcpyAsync(groups) failed");
                     rc = MIMEO_ERR_HIP;
                     break;
                 }
-                if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)X.hsps.p,
-                                              (const uint32_t *)X.hsp_unit.p, nh, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain,
+                if ((rc = chain_gapped_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_hsp *)g_ext.hsps.p,
+                                              (const uint32_t *)g_ext.hsp_unit.p, nh, p, g_scratch, (mimeo_alignment *)g_aln.p, &ms_chain,
                                               &ms_gapped)))
                     break;
                 // the alignments are a few thousand records in an array of one slot per HSP: packed on the device, then read
                 if ((rc = g_dense.reserve(nh * sizeof(mimeo_alignment)))) break;
                 dense_alignments_device((Group *)g_groups.p, (uint32_t)groups.size(), (const mimeo_alignment *)g_aln.p,
                                         (mimeo_alignment *)g_dense.p);
-                if (hipMemcpyAsync(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, sk) != hipSuccess ||
-                    hipStreamSynchronize(sk) != hipSuccess) {
+                if (hipMemcpyAsync(groups.data(), g_groups.p, groups.size() * sizeof(Group), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) {
                     set_error("HIP error while reading back alignments");
                     rc = MIMEO_ERR_HIP;
                     break;
                 }
                 const uint64_t naln_total = (uint64_t)groups.back().job0 + groups.back().naln;
                 std::vector<mimeo_alignment> host_aln(naln_total);
-                if (naln_total && (hipMemcpyAsync(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost, sk) != hipSuccess ||
-                                   hipStreamSynchronize(sk) != hipSuccess)) {
+                if (naln_total && (hipMemcpyAsync(host_aln.data(), g_dense.p, naln_total * sizeof(mimeo_alignment), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                   hipStreamSynchronize(st) != hipSuccess)) {
                     set_error("HIP error while reading back alignments");
                     rc = MIMEO_ERR_HIP;
                     break;
                 }
                 for (size_t gi = 0; gi < groups.size(); gi++) {
                     const Group &g = groups[gi];
-                    if (getenv("MIMEO_K6_STATS") && gi < 24)
+                    if (sw.k6_stats && gi < 24)
                         fprintf(stderr, "  [grp] t%u q%u %c hsps %llu nchain %u naln %u\n", g.tid, g.qid, g.minus ? '-' : '+',
                                 (unsigned long long)(g.hsp_end - g.hsp_begin), g.nchain, g.naln);
-                    if (g.overflow) {
-                        char msg[256];
-                        snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns, or "
-                                 "score beyond int32: not supported", g.tid, g.qid, g.minus ? '-' : '+');
-                        set_error(msg);
-                        rc = MIMEO_ERR_LIMIT;
-                        break;
+                    if (g.overflow) {   // this pair hit a limit: it is left out, the others go on (utils.py:125-128: no `set -e`)
+                        record_failure(pair_of[gi], g.tid, g.qid, g.minus ? '-' : '+', failed);
+                        continue;
                     }
                     g_stats.chained_hsps += g.nchain;
-                    auto &dst = per_pair[units[b0 + gi].pair];
+                    auto &dst = per_pair[pair_of[gi]];
                     dst.insert(dst.end(), host_aln.begin() + g.job0, host_aln.begin() + g.job0 + g.naln);
                 }
             }
-            if (timing) {
+            if (sw.timing) {
                 auto tb2 = std::chrono::steady_clock::now();
-                fprintf(stderr, "[timing] batch of %zu units%s: next start + tails %.2f ms (device heavy %.2f + tails %.2f so far), chain + gapped + read-back %.2f ms (device %.2f + %.2f so far)\n",
-                        bp.work.size(), overlap ? " (overlapped)" : "", std::chrono::duration<double, std::milli>(tb1 - tb0).count(), est.ms_heavy, est.ms_tails,
+                fprintf(stderr, "[timing] batch of %zu units: heavy + tails %.2f ms (device heavy %.2f + tails %.2f so far), chain + gapped + read-back %.2f ms (device %.2f + %.2f so far)\n",
+                        work.size(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(), est.ms_heavy, est.ms_tails,
                         std::chrono::duration<double, std::milli>(tb2 - tb1).count(), ms_chain, ms_gapped);
             }
+            b0 = b1;
         }
-        set_thread_stream(nullptr);
-        if (rc) { (void)hipStreamSynchronize(st); if (g_tail_stream) (void)hipStreamSynchronize(g_tail_stream); }   // a started batch drains
+        if (rc) (void)hipStreamSynchronize(st);   // a started batch drains
         cache.clear();
         ms_index += cache.ms;
         g_stats.index_blocks++;
     }
     }   // !packed
     if (rc) return rc;
+    for (uint64_t k = 0; k < npairs; k++)
+        if (failed[k]) per_pair[k].clear();   // a pair that hit a limit on one strand yields no rows at all (its lastz run failed)
+    // a pair's plus-strand alignments come before its minus-strand ones whichever batch made them
+    for (auto &v : per_pair)
+        std::stable_sort(v.begin(), v.end(), [](const mimeo_alignment &a, const mimeo_alignment &b) { return a.qstrand < b.qstrand; });
     uint64_t total = 0;
     for (auto &v : per_pair) total += v.size();
     mimeo_alignment *res = (mimeo_alignment *)malloc((total ? total : 1) * sizeof(mimeo_alignment));

@@ -104,3 +104,58 @@ def shard_pairs_by_target(pairs, cost_of_target, world, rank):
         owner[t] = r
         load[r] += cost_of_target[t]
     return [(t, q) for t, q in pairs if owner[t] == rank]
+
+
+PLUS, MINUS, BOTH = 1, 2, 3
+
+
+def plus_owner(a, b, nscaf):
+    """Which of the rows a, b computes the plus-strand unit of the unordered scaffold pair {a, b} of a self job (and emits it
+    for both orders: the HSP sets of (a, b, +) and (b, a, +) are transposes of one another, DESIGN.md "Shared plus strand").
+    Circulant dealing: row a takes the pairs {a, a + d mod S} for d < S / 2, so every row owns (S - 1) / 2 of them; the
+    pairs at distance exactly S / 2 (S even) go to the even member, or to the smaller one when both have the same parity."""
+    if a == b:
+        return a
+    d = (b - a) % nscaf
+    if 2 * d < nscaf:
+        return a
+    if 2 * d > nscaf:
+        return b
+    lo, hi = min(a, b), max(a, b)
+    if (lo % 2) != (hi % 2):
+        return lo if lo % 2 == 0 else hi
+    return lo
+
+
+def units_of_row(t, nscaf):
+    """The units of target row t in a self job of `nscaf` scaffolds, as (target, query, strands) for mimeo_align_units:
+    every minus-strand unit (t, q, -), the row's own (t, t, +), and for every unordered pair {t, q} this row owns the
+    plus-strand unit in BOTH orders.  The rows together name each of the 2 S^2 units of the job exactly once."""
+    units = []
+    for q in range(nscaf):
+        own = plus_owner(t, q, nscaf) == t
+        units.append((t, q, BOTH if own else MINUS))
+    for q in range(nscaf):
+        if q != t and plus_owner(t, q, nscaf) == t:
+            units.append((q, t, PLUS))
+    return units
+
+
+def deal_units(nscaf, cost_of_target, world, rank):
+    """A rank's share of a self job: target rows by longest-processing-time (as shard_pairs_by_target), each with
+    units_of_row.  No data-path collective: a row's units need nothing from another rank; the rows' alignments meet in the
+    all-gatherv at the end."""
+    rows = list(range(nscaf))
+    if world > 1:
+        targets = sorted(rows, key=lambda t: (-cost_of_target[t], t))
+        load = [0] * world
+        owner = {}
+        for t in targets:
+            r = min(range(world), key=lambda k: (load[k], k))
+            owner[t] = r
+            load[r] += cost_of_target[t]
+        rows = [t for t in rows if owner[t] == rank]
+    units = []
+    for t in rows:
+        units += units_of_row(t, nscaf)
+    return units

@@ -142,6 +142,37 @@ def align_pairs(A, B, pairs, params=None):
     return _ffi.take(ptr, n, _ffi.ALIGNMENT)
 
 
+def align_units(A, B, units, params=None):
+    """units: iterable of (target index in A, query index in B or A, strands) with strands = 1 plus, 2 minus, 3 both
+    (masked with params.strand): mimeo_align_units — a rank's share of a sharded self job (dist.deal_units)."""
+    p = params or default_params()
+    un = np.asarray(list(units), dtype=np.uint32).reshape(-1, 3)
+    pt, pq = np.ascontiguousarray(un[:, 0]), np.ascontiguousarray(un[:, 1])
+    ps = np.ascontiguousarray(un[:, 2].astype(np.uint8))
+    ptr, n = C.c_void_p(), C.c_uint64()
+    _ffi.check(_ffi.load().mimeo_align_units(A._h, B._h if B is not None else None, pt.ctypes.data, pq.ctypes.data, ps.ctypes.data,
+                                             len(pt), C.byref(p), C.byref(ptr), C.byref(n)))
+    return _ffi.take(ptr, n, _ffi.ALIGNMENT)
+
+
+def failed_pairs():
+    """Pairs of the last align_pairs / align_units call that hit a documented limit and were left out (the reference's script
+    loses only the failing lastz run's rows: utils.py:125-128): [(index into the call's pair list, error code)]."""
+    lib = _ffi.load()
+    n = C.c_uint64()
+    _ffi.check(lib.mimeo_get_failed_pairs(None, None, 0, C.byref(n)))
+    if not n.value:
+        return []
+    idx = np.zeros(n.value, dtype=np.uint64)
+    code = np.zeros(n.value, dtype=np.int32)
+    _ffi.check(lib.mimeo_get_failed_pairs(idx.ctypes.data, code.ctypes.data, n.value, C.byref(n)))
+    return list(zip(idx.tolist(), code.tolist()))
+
+
+def last_error():
+    return _ffi.load().mimeo_last_error().decode()
+
+
 def coverage_collapse(intervals, chrom_len, min_cov, min_len):
     """intervals: structured array (_ffi.INTERVAL) or (n,3) ints of (chrom id, start, end)."""
     iv = np.asarray(intervals)

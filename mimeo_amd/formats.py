@@ -84,9 +84,16 @@ def tab_blocks(alns, tnames, qnames, min_len, min_idt):
     with np.errstate(divide='ignore', invalid='ignore'):
         val = np.where(idd > 0, 100.0 * idn / idd, 0.0)
     # lastz prints identity `%.1f%%`; the reference strips the % (wrappers.py:1040) and awk compares the printed
-    # one-decimal value with minIdt (wrappers.py:1052): format first, compare the formatted number
-    pct = ['%.1f' % v for v in val.tolist()]
-    keep = (te - ts >= min_len) & (np.array([float(x) for x in pct]) >= min_idt)   # length1 = end1 - start1 + 1 = te - ts
+    # one-decimal value with minIdt (wrappers.py:1052): format first, compare the formatted number.  tenths = the digits
+    # '%.1f' prints: round-half-even of the double's exact value — floor(10 v + 1/2) away from a tie, Python's own
+    # formatting within 1e-6 of one (10 v carries a rounding error of its own there)
+    x10 = val * 10.0
+    fl = np.floor(x10)
+    frac = x10 - fl
+    tenths = (fl + (frac > 0.5)).astype(np.int64)
+    for i in np.flatnonzero(np.abs(frac - 0.5) < 1e-6).tolist():
+        tenths[i] = int(('%.1f' % val[i]).replace('.', ''))
+    keep = (te - ts >= min_len) & (tenths >= int(min_idt) * 10 if float(min_idt) == int(min_idt) else tenths / 10.0 >= min_idt)   # length1 = end1 - start1 + 1 = te - ts
     idx = np.flatnonzero(keep)
     if idx.size == 0:
         return {}, np.zeros((0, 4), dtype=np.int64)
@@ -94,11 +101,13 @@ def tab_blocks(alns, tnames, qnames, min_len, min_idt):
     pair = tid << 32 | qid
     order = np.lexsort((ts[idx], pair))          # name1 is constant inside a block: start1 numeric, then the whole line
     idx, tid, qid, pair = idx[order], tid[order], qid[order], pair[order]
-    s1 = ts[idx] + 1
-    lines = ['%s\t+\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%s' % (tnames[t], a, b, qnames[q], '-' if m else '+', c, d, sc, pct[i])
-             for t, a, b, q, m, c, d, sc, i in zip(tid.tolist(), s1.tolist(), te[idx].tolist(), qid.tolist(),
-                                                   alns['qstrand'][idx].tolist(), (alns['qstart'].astype(np.int64)[idx] + 1).tolist(),
-                                                   alns['qend'][idx].tolist(), alns['score'][idx].tolist(), idx.tolist())]
+    s1, e1 = ts[idx] + 1, te[idx]
+    tn, qn = np.array(list(tnames), dtype=object)[tid].tolist(), np.array(list(qnames), dtype=object)[qid].tolist()
+    sign = np.array(['+', '-'], dtype=object)[(alns['qstrand'][idx] != 0).astype(np.int64)].tolist()
+    t10 = tenths[idx]
+    lines = ['%s\t+\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d.%d' % r
+             for r in zip(tn, s1.tolist(), e1.tolist(), qn, sign, (alns['qstart'].astype(np.int64)[idx] + 1).tolist(),
+                          alns['qend'][idx].tolist(), alns['score'][idx].tolist(), (t10 // 10).tolist(), (t10 % 10).tolist())]
     # ties on (pair, start1) fall to sort's last-resort comparison of the whole line, byte by byte
     same = np.flatnonzero((pair[1:] == pair[:-1]) & (s1[1:] == s1[:-1]))
     if same.size:

@@ -8,7 +8,9 @@ C2-like synthetic genomes (mimeo_amd.synth: SURVEY §8d — 40 families, diverge
 oracle finishes in minutes: S scaffolds of L bases, every ordered pair, both strands — the (A, A) plus strand included: its
 chain is the whole-scaffold diagonal alone, so nothing is left to differ there.
 
-    python scripts/box_vs_path.py [S] [L] [repeat_frac] [seed]   -> a JSON line per configuration
+    python scripts/box_vs_path.py [S] [L] [repeat_frac] [seed] [families] [tandem arrays per scaffold]   -> a JSON line
+(tandem arrays: 8-30 diverged copies of a 150-900 bp unit in a row, the same few units in every scaffold — chained HSPs on
+neighbouring diagonals inside one box are the case where the two rules could part)
 """
 import ctypes as C
 import json
@@ -95,6 +97,27 @@ def main():
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 50
     fams = int(sys.argv[5]) if len(sys.argv) > 5 else 40
     names, arrs = synth_genome(seed, S * L, S, repeat_frac=frac, families=fams)
+    ntand = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    if ntand:
+        rng = np.random.default_rng(seed + 7)
+        units = [rng.integers(0, 4, size=int(rng.integers(150, 900)), dtype=np.uint8) for _ in range(3)]
+        acgt = np.frombuffer(b'ACGT', np.uint8)
+        arrs = [a.copy() for a in arrs]
+        for a in arrs:
+            for _ in range(ntand):
+                u = units[int(rng.integers(0, 3))]
+                copies = []
+                for _c in range(int(rng.integers(8, 31))):
+                    c = u.copy()
+                    m = rng.random(c.size) < rng.random() * 0.12
+                    c[m] = (c[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+                    if rng.random() < 0.3:   # an indel of 1-20 bases between copies
+                        c = np.concatenate([c, rng.integers(0, 4, size=int(rng.integers(1, 21)), dtype=np.uint8)]) if rng.random() < 0.5 else c[:-int(rng.integers(1, 21))]
+                    copies.append(c)
+                arr = acgt[np.concatenate(copies)]
+                if arr.size < a.size // 2:
+                    pos = int(rng.integers(0, a.size - arr.size))
+                    a[pos:pos + arr.size] = arr
     seqs = [a.tobytes() for a in arrs]
     lib()
     pairs = [(t, q) for t in range(S) for q in range(S)]
@@ -117,7 +140,7 @@ def main():
     setb = set(map(tuple, box_all[cols].tolist()))
     setp = set(map(tuple, path_all[cols].tolist()))
     print(json.dumps({
-        'genome': {'scaffolds': S, 'scaffold_bp': L, 'repeat_frac': frac, 'families': fams, 'seed': seed},
+        'genome': {'scaffolds': S, 'scaffold_bp': L, 'repeat_frac': frac, 'families': fams, 'seed': seed, 'tandem_arrays_per_scaffold': ntand},
         'pair_strands': 2 * len(pairs), 'anchors': int(tot_b[0]),
         'box_rule': {'skipped': int(tot_b[1]), 'alignments': int(tot_b[3]), 'tab_rows_kept': kb, 'regions': len(rb)},
         'path_rule': {'skipped': int(tot_p[1]), 'alignments': int(tot_p[3]), 'tab_rows_kept': kp, 'regions': len(rp),

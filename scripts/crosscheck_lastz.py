@@ -33,9 +33,30 @@ def reference_argv(target_fa, query_fa, out, hspthresh=3000):
             '--step=1', '--strand=both', '--hspthresh=%d' % hspthresh, '--output=' + out, '--verbosity=0']
 
 
+def _is_our_shim(path):
+    """scripts/lastz and scripts/bedtools of THIS repo are drop-ins that call the engine: a binary found under the repo, or a
+    script that starts mimeo_amd's shims, is not the reference's tool — the A/B check would compare the engine with itself
+    and report false parity evidence."""
+    if not path:
+        return False
+    real = os.path.realpath(path)
+    if real == ROOT or real.startswith(ROOT + os.sep):
+        return True
+    try:
+        with open(real, 'rb') as f:
+            head = f.read(4096)
+    except OSError:
+        return False
+    return head.startswith(b'#!') and (b'mimeo_amd.lastz_shim' in head or b'mimeo_amd.bedtools_shim' in head or b'mimeo_amd' in head)
+
+
 def probe(lzpath='lastz'):
-    """{'lastz': path or None, 'bedtools': ..., 'trf': ..., 'status': ...} — no process is started."""
+    """{'lastz': path or None, 'bedtools': ..., 'trf': ..., 'status': ...} — no process is started.  This repo's own
+    drop-ins (scripts/lastz, scripts/bedtools) do not count as the reference's tools."""
     found = {tool: shutil.which(path) for tool, path in (('lastz', lzpath), ('bedtools', 'bedtools'), ('trf', 'trf'))}
+    for tool in ('lastz', 'bedtools'):
+        if _is_our_shim(found[tool]):
+            found[tool] = None
     found['status'] = 'lastz present: run scripts/crosscheck_lastz.py for the A/B diff' if found['lastz'] else 'lastz absent: parity unpinned'
     return found
 

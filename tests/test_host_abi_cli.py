@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     assert declared == set(_ffi.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.mimeo_abi_version() == _ffi.ABI_VERSION == 2
+    assert lib.mimeo_abi_version() == _ffi.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header():
@@ -93,3 +93,45 @@ def test_crosscheck_lastz_probe_and_row_diff(tmp_path):
     ours = [row(1, 100, 5, 104, 9000, '90.0%'), row(200, 300, 7, 107, 8100, '90.0%'), row(600, 700, 1, 101, 7000, '90.0%')]
     d = X.compare(real, ours)
     assert d == {'rows_lastz': 3, 'rows_ours': 3, 'identical': 1, 'same_coordinates_other_score': 1, 'only_lastz': 1, 'only_ours': 1}
+
+
+def test_lastz_probe_does_not_take_the_repos_own_shim_for_the_reference_tool(monkeypatch):
+    """scripts/lastz is this repo's drop-in for the reference's --lzpath: with it on PATH (as INTEGRATION.md suggests) the
+    A/B cross-check must still say that no real lastz is there — comparing the engine with itself is no parity evidence."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import crosscheck_lastz
+    monkeypatch.setenv('PATH', os.path.join(ROOT, 'scripts') + os.pathsep + os.environ.get('PATH', ''))
+    for arg in ('lastz', os.path.join(ROOT, 'scripts', 'lastz')):
+        found = crosscheck_lastz.probe(arg)
+        assert found['lastz'] is None and found['bedtools'] is None and 'parity unpinned' in found['status']
+
+
+def test_unit_dealing_names_every_unit_once():
+    """dist.units_of_row / deal_units: the rows of a self job name each of the 2 S^2 (target, query, strand) units exactly once,
+    an unordered pair's plus-strand unit sits in one row in both orders, rows carry nearly equal numbers of them, and the
+    ranks' shares are disjoint and complete."""
+    from mimeo_amd import dist
+    for S in (1, 2, 5, 6, 10, 100):
+        seen = {}
+        per_row = []
+        for t in range(S):
+            units = dist.units_of_row(t, S)
+            owned = 0
+            for a, b, m in units:
+                for bit in (1, 2):
+                    if m & bit:
+                        assert (a, b, bit) not in seen
+                        seen[(a, b, bit)] = t
+                if a != t:   # a transposed plus-strand unit: its partner is in the same row
+                    assert m == 1 and (t, a, 1) in seen and seen[(t, a, 1)] == t
+                    owned += 1
+            per_row.append(owned)
+        assert len(seen) == 2 * S * S
+        assert max(per_row) - min(per_row) <= 1 and sum(per_row) == (S * S - S) // 2
+    S, W = 10, 4
+    cost = {t: 1 + t % 3 for t in range(S)}
+    shares = [dist.deal_units(S, cost, W, r) for r in range(W)]
+    allu = [u for sh in shares for u in sh]
+    named = {(a, b, bit) for a, b, m in allu for bit in (1, 2) if m & bit}
+    assert len(named) == 2 * S * S and sum(bin(m).count('1') for _, _, m in allu) == 2 * S * S
