@@ -215,7 +215,9 @@ struct ExtBatch {
     uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0, cap_w_ = 0;
     double expect_hits_ = 0;
     uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;
-    bool v1_ = false, started_ = false;
+    bool v1_ = false, started_ = false, k4_stats_ = false;
+    uint32_t k34_dbg_ = 0, qw_blocks_ = 256;
+    int k4_variant_ = 0;
     void *q_ = nullptr;   // ExtQueues of the batch (k4_device.h), owned
     int enqueue_heavy();
     uint64_t queue_bytes() const;   // device bytes the queues of the batch take at the current capacities

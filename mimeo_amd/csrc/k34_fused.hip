@@ -23,6 +23,7 @@
 // frames of a tile once more per further query segment (Infinity Cache).
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "k4_device.h"
@@ -225,6 +226,17 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 return;
             }
         }
+        // my share of the tile's query offsets (relative to its first entry), kept in registers for all its segments: from the
+        // copy the count prologue staged in LDS (first pass; read before the frames overwrite it: the segment loop opens with
+        // a barrier), or from the offset array
+        constexpr int NRO = (TILE_WORDS + THREADS) / THREADS;   // 4097 offsets over the workgroup's threads
+        uint32_t ro[NRO];
+#pragma unroll
+        for (int i = 0; i < NRO; i++) {
+            const uint32_t k = threadIdx.x + (uint32_t)i * THREADS;
+            ro[i] = 0;
+            if (k <= TILE_WORDS) ro[i] = (HEAVY ? qoff[k] : (k < TILE_WORDS ? (reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[k] : q0 + nQ)) - q0;
+        }
         const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
         const uint32_t nchunks = (nT + TCH - 1) / TCH;
         // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
@@ -242,9 +254,10 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
             __syncthreads();  // every wavefront is through with the previous segment (and with the count prologue's use of the frame area)
             // the tile's offsets relative to this segment, clamped to it: key w's entries inside the segment are sQ[w] .. sQ[w + 1]
-            for (uint32_t k = threadIdx.x; k <= TILE_WORDS; k += THREADS) {
-                const uint32_t o = qoff[k] - q0;   // qoff[TILE_WORDS] is the next tile's first entry (the array has 2^24 + 1 of them)
-                sQ[k] = (qoff_t)(min(max(o, qs), qe) - qs);
+#pragma unroll
+            for (int i = 0; i < NRO; i++) {
+                const uint32_t k = threadIdx.x + (uint32_t)i * THREADS;
+                if (k <= TILE_WORDS) sQ[k] = (qoff_t)(min(max(ro[i], qs), qe) - qs);
             }
             {
                 const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
@@ -396,23 +409,25 @@ static const dim3 HEAVY_GRID(HEAVY_MAX, HEAVY_SPLIT, HEAVY_QSPLIT);
 constexpr uint32_t QSEG_FIRST = 1280, QSEG_HEAVY = 1024;
 
 int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
-                      hipStream_t st) {
+                      hipStream_t st, uint32_t dbg) {
     FusedArgs A;
     A.T = w.ti; A.Q = w.qi; A.q = q; A.tab = tab;
     A.tlen = w.d.T.len; A.qlen = w.d.Q.len; A.tsoft = w.d.T.svt != nullptr ? 1u : 0u;
     A.unit = unit; A.same = w.d.same;
     A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
     A.heavy_pass = 0; A.heavy_base = 0;
-    A.dbg = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
+    A.dbg = dbg;   // MIMEO_K34_DEBUG, read once per batch by the caller
     constexpr size_t smem_heavy = FusedCfg<512, QSEG_HEAVY, true>::SMEM, smem_first = FusedCfg<512, QSEG_FIRST, false>::SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_FIRST, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_first));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_HEAVY, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_heavy));
-        attr_done = true;
-    }
+    static std::once_flag attr_once;   // the library may be driven from any one thread at a time: still set exactly once
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_FIRST, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_first);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(k34_scan_extend<512, QSEG_HEAVY, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_heavy);
+    });
+    HIP_TRY(attr_err);
     // measured on a C4 unit (two segments per tile at 1280, three at 1216 and 1024): 1.44 / 1.51 / 1.54 ms for the heavy phase
     hipLaunchKernelGGL((k34_scan_extend<512, QSEG_FIRST, false>), dim3(NTILE), dim3(512), smem_first, st, A);
     A.heavy_pass = 1;

@@ -616,7 +616,7 @@ const uint32_t *group_table_device() {
 
 // fused heavy kernel (k34_fused.hip)
 int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
-                      hipStream_t st);
+                      hipStream_t st, uint32_t dbg);
 void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
@@ -719,7 +719,12 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
         HIP_TRY(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     }
+    // development / test switches: read once per batch, never per launch
     v1_ = getenv("MIMEO_HEAVY") && !strcmp(getenv("MIMEO_HEAVY"), "v1");
+    k34_dbg_ = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
+    k4_variant_ = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 0;
+    qw_blocks_ = getenv("MIMEO_QW_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("MIMEO_QW_BLOCKS"))) : 256u;
+    k4_stats_ = getenv("MIMEO_K4_STATS") != nullptr;
     int rc;
     if ((rc = units.reserve((size_t)nunits * sizeof(UnitDesc))) || (rc = ctr.reserve(sizeof(ExtCounters))) ||
         (rc = unit_hits.reserve((size_t)nunits * 8)) || (rc = nsel.reserve(16)) ||
@@ -815,11 +820,11 @@ int ExtBatch::enqueue_heavy() {
                     kev.push_back(e);
                 }
                 HIP_TRY(hipEventRecord(kev[2 * u], st));
-                if ((rc = launch_fused_unit(w, u, q, p, tab, st))) return rc;
+                if ((rc = launch_fused_unit(w, u, q, p, tab, st, k34_dbg_))) return rc;
                 HIP_TRY(hipEventRecord(kev[2 * u + 1], st));
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
                 const unsigned long long *d_n = q.ctr->nwalk;
-                static const uint32_t qblocks = getenv("MIMEO_QW_BLOCKS") ? (uint32_t)atoi(getenv("MIMEO_QW_BLOCKS")) : 256u;
+                const uint32_t qblocks = qw_blocks_;
 #define K4_QUEUE(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3(qblocks), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)q.walkq, q.walk_cap, \
                            p->xdrop, p->hspthresh, p->transitions, tab, q, u, 0, d_n)
                 if (slim) K4_QUEUE(9);
@@ -832,7 +837,7 @@ int ExtBatch::enqueue_heavy() {
                 if ((rc = join_hits(jc, w.ti, w.qi, p->transitions, hits, &nh, nullptr))) return rc;
                 if (!nh) continue;
                 uint64_t nb = std::min<uint64_t>((nh + FAST_THREADS - 1) / FAST_THREADS, 1024);
-                const int variant = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 0;
+                const int variant = k4_variant_;
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)hits.p, nh, \
                            p->xdrop, p->hspthresh, p->transitions, tab, q, u, (int)w.d.same, (const unsigned long long *)nullptr)
@@ -925,10 +930,10 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             over = c.ncand > cap_c;
         }
         HIP_TRY(hipGetLastError());
-        if (getenv("MIMEO_K34_DEBUG") && (atoi(getenv("MIMEO_K34_DEBUG")) & 8))
+        if (k34_dbg_ & 8)
             fprintf(stderr, "[k34] passed on because: left stop unproven %llu, right %llu, bound %llu, alarm %llu; ONLY alarm %llu, only left %llu, only right %llu, only bound %llu\n",
                     c.dbg[0], c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7]);
-        if (getenv("MIMEO_K4_STATS"))
+        if (k4_stats_)
             fprintf(stderr, "[k4] units %u walk queue %llu walked %llu generic %llu long %llu followers %llu candidates %llu hsps %llu%s\n", nunits,
                     c.nwalk_total, c.nwalked, (unsigned long long)nm, c.nlong, (unsigned long long)nf, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
         if (!over) {

@@ -1250,6 +1250,8 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
     } else {
         uint32_t bmax = 8192u / ngroups;  // anchors per group and round (200 units: 32 -> one large round and a short one)
         if (getenv("MIMEO_K6_BMAX")) bmax = (uint32_t)atoi(getenv("MIMEO_K6_BMAX"));
+        const char *kmode = getenv("MIMEO_K6_KERNEL");       // development switches: read once per call, not per round
+        const bool k6_stats = getenv("MIMEO_K6_STATS") != nullptr;
         bmax = bmax < 1 ? 1 : (bmax > MAX_BATCH ? MAX_BATCH : bmax);
         if ((rc = g_anchors.reserve(nhsps * sizeof(uint2)))) return rc;
         if ((rc = g_packed.reserve(nhsps * 8))) return rc;
@@ -1279,7 +1281,6 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                 // MIMEO_K6_KERNEL (development A/B): "dp4" = the four-wavefront kernel then wave_half_extend<16>, "dp" = the
                 // latter alone; default = the lean single-wavefront kernel (its dead-cell arithmetic needs the
                 // penalties to stay far below 2^29 / 1024)
-                const char *kmode = getenv("MIMEO_K6_KERNEL");
                 const bool lean_ok = p->gap_extend <= (1 << 16) && p->gap_open <= (1 << 24) && p->ydrop <= (1 << 28);
                 if (lean_ok && !kmode) {
                     hipLaunchKernelGGL(k6_dp1, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
@@ -1308,7 +1309,7 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                                            (uint32_t *)g_any.p, p->gap_open, p->gap_extend, p->ydrop);
                 }
             }
-            if (getenv("MIMEO_K6_STATS") && h[0]) {
+            if (k6_stats && h[0]) {
                 std::vector<DpJob> hj(h[0]);
                 std::vector<HalfResult> hall((size_t)nhsps * 2), hr(h[0]);
                 HIP_TRY(hipStreamSynchronize(st));
