@@ -383,9 +383,12 @@ def main():
         except Exception as e:   # the calibration must never cost the bench line
             standalone = {'error': repr(e)}
     if dist.rank == 0:
-        launches = max(1, agg['scan_launches'])
-        t_fill = agg['ms_scan_fill'] / 1e3 / launches          # s per seed-scan (fill) launch, HIP events
-        b_alg = agg['scan_bytes_algorithmic'] / launches        # SURVEY §8(d) B_scan per launch
+        # the seed-scan kernel K34 takes a whole batch of units per launch: duration by HIP events around each launch (first pass +
+        # split pass), algorithmic bytes = SURVEY §8(d) B_scan summed over the units of the launch
+        launches = max(1, agg.get('scan_kernel_launches') or agg['scan_launches'])
+        units = max(1, agg['scan_launches'])
+        t_fill = agg['ms_scan_fill'] / 1e3 / launches          # s per seed-scan launch, HIP events
+        b_alg = agg['scan_bytes_algorithmic'] / launches        # B_scan per launch
         achieved = b_alg / t_fill / 1e9 if t_fill > 0 else 0.0
         traffic = pmc_traffic(args.workload)
         scaf_mbp = total_bp / nscaf / 1e6
@@ -414,13 +417,14 @@ def main():
                                    % (args.workload.upper(), mode, total_bp // 1_000_000, '' if B is None else ' x2 (A, B)', nscaf,
                                       scaf_mbp, seed if B is None else '%d/%d' % (seed, seed_b), what),
                        'pairs': len(pairs), 'pair_strands_rank0': int(st['pair_strands']), 'parallelism': par},
-            'roofline': {'kernel': 'k34_scan_extend (seed scan fused with the gap-free pre-filter; one launch per (target, query, strand) unit)',
+            'roofline': {'kernel': 'k34_scan_extend (seed scan fused with the gap-free pre-filter; one launch per BATCH of (target, query, strand) units: grid.y = unit)',
                          'bound': 'valu', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                         'valu': valu_issue(t_fill * 1e3) if args.workload in ('c4', 'c4job') else None,
-                         'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r02_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
-                         'traffic_frac': (traffic / t_fill / 8e12) if (traffic and t_fill > 0) else None,
+                         'valu': valu_issue(t_fill * 1e3 * launches / units) if args.workload in ('c4', 'c4job') else None,
+                         'traffic': (traffic * units / launches) if traffic else None, 'traffic_unit': 'HBM bytes per launch = per-unit bytes x units per launch (rocprofv3 PMC on one C4 unit, profiles/r02_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
+                         'traffic_frac': (traffic * units / launches / t_fill / 8e12) if (traffic and t_fill > 0) else None,
                          'kernel_bytes_per_launch': agg['scan_bytes_kernel'] / launches,
                          'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches),
+                         'units_per_launch': units / launches, 'ms_per_unit': t_fill * 1e3 * launches / units,
                          'note': 'achieved / peak / frac = the HBM roofline SURVEY 8(d) defines: B_scan per unit / HIP-event duration of the launch / 8 TB/s.  '
                                  'The fused kernel never writes the hit array that byte model charges for; what bounds it is VALU issue of the '
                                  'pre-filter (bound = valu; the valu block: instructions per launch x cycles per instruction of its opcode mix / '

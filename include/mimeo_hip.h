@@ -124,7 +124,7 @@ typedef struct mimeo_stats {
     double ms_gapped;
     double ms_collapse;
     double ms_total;              /* host wall time of the call                            */
-    uint64_t scan_launches;       /* number of seed-scan kernel launches (one per unit) timed in ms_scan_fill */
+    uint64_t scan_launches;       /* units (target, query, strand) the seed-scan kernel worked off in ms_scan_fill (one launch per unit until ABI 2) */
     double ms_scan_fill;          /* HIP-event time of the seed-scan kernels (K34, the roofline kernel), back to back per batch */
     uint64_t index_blocks;        /* blocks the pair matrix was cut into so that the seed indexes fit in memory (1 = none) */
     uint64_t batches;             /* batches of units the call was worked off in (tails, chain and gapped stage run once per batch) */
@@ -132,6 +132,7 @@ typedef struct mimeo_stats {
     uint64_t walked_hits;         /* seed hits the pre-filter could not dismiss: walked exactly */
     uint64_t followers;           /* hits with an earlier seed hit of their diagonal in reach: resolved after one sort per batch */
     uint64_t super_units;         /* units of super-scaffolds (small scaffolds packed behind spacers: fragmented assemblies); 0 = the call ran one unit per scaffold pair and strand */
+    uint64_t scan_kernel_launches; /* launches of the seed-scan kernel K34 (first pass) in ms_scan_fill: one per BATCH of units (ABI 3) */
 } mimeo_stats;
 
 typedef struct mimeo_genome mimeo_genome; /* opaque: device-resident packed scaffolds */

@@ -32,7 +32,7 @@ class Stats(C.Structure):
                                           'query_bases_scanned', 'scan_bytes_algorithmic', 'scan_bytes_kernel')] + \
                [(n, C.c_double) for n in ('ms_index', 'ms_scan', 'ms_extend', 'ms_chain', 'ms_gapped', 'ms_collapse',
                                           'ms_total')] + \
-               [('scan_launches', C.c_uint64), ('ms_scan_fill', C.c_double), ('index_blocks', C.c_uint64), ('batches', C.c_uint64), ('queue_reruns', C.c_uint64), ('walked_hits', C.c_uint64), ('followers', C.c_uint64), ('super_units', C.c_uint64)]
+               [('scan_launches', C.c_uint64), ('ms_scan_fill', C.c_double), ('index_blocks', C.c_uint64), ('batches', C.c_uint64), ('queue_reruns', C.c_uint64), ('walked_hits', C.c_uint64), ('followers', C.c_uint64), ('super_units', C.c_uint64), ('scan_kernel_launches', C.c_uint64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != 'reserved'}

@@ -302,6 +302,7 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
     g_stats.ms_scan = est.ms_heavy;
     g_stats.ms_scan_fill = est.ms_k34;
     g_stats.scan_launches = est.heavy_launches;
+    g_stats.scan_kernel_launches = est.heavy_kernel_launches;
     g_stats.ms_extend = est.ms_tails;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MIMEO_OK;

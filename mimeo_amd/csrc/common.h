@@ -173,9 +173,19 @@ struct UnitWork {  // host side: a unit with the seed indexes its heavy kernel r
     UnitDesc d;
     IndexView ti, qi;
 };
+// a unit of the batch as the heavy kernels see it (K34 over all units in one launch; the walk-queue kernel likewise)
+struct FusedUnit {
+    IndexView T, Q;
+    StrandView Tv, Qv;
+    uint32_t unit;        // number in the batch (index into the UnitDesc table, tag of every record)
+    uint32_t same;        // target and query are the same strand: the main diagonal belongs to k4_diag0
+    uint64_t walk_base;   // this unit's region of the walk queue: eight shards of walk_cap entries from here
+    uint64_t walk_cap;
+};
+
 struct ExtStats {
     uint64_t seed_hits = 0, walked = 0, walk_queue = 0, followers = 0, candidates = 0, reruns = 0;
-    uint64_t scan_bytes_algorithmic = 0, scan_bytes_kernel = 0, heavy_launches = 0;
+    uint64_t scan_bytes_algorithmic = 0, scan_bytes_kernel = 0, heavy_launches = 0, heavy_kernel_launches = 0;
     float ms_heavy = 0, ms_k34 = 0, ms_walk = 0, ms_tails = 0;  // ms_k34: the K34 launches alone (event pair per launch)  // ms_walk: the exact walks of the walk queue (part of ms_tails)
 };
 // The extension stage of one batch: heavy kernel per unit (K34 fused seed scan + pre-filter + exact walks; or, for
@@ -211,11 +221,16 @@ struct ExtBatch {
     mimeo_params p_;
     std::vector<uint32_t> h_selfs_, mirror_dst_;
     std::vector<UnitDesc> h_units_;
+    std::vector<FusedUnit> h_funits_;
     DeviceBuf mirror;     // mirror_dst_ on the device + one counter
-    uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0, cap_w_ = 0;
+    DeviceBuf funits, nwalk_u;   // per-unit table of the heavy kernels (FusedUnit); walk-queue counters per unit and shard + split-pass tile counts
+    std::vector<uint64_t> walk_cap_u_;   // walk-queue capacity per unit and shard
+    uint64_t walk_entries_ = 0;          // ... all regions together
+    uint32_t nactive_ = 0;               // units of the batch that launch the heavy kernels
+    uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0;
     double expect_hits_ = 0;
     uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;
-    bool v1_ = false, started_ = false, k4_stats_ = false;
+    bool v1_ = false, started_ = false, k4_stats_ = false, splittable_ = false;
     uint32_t k34_dbg_ = 0, qw_blocks_ = 256;
     int k4_variant_ = 0;
     void *q_ = nullptr;   // ExtQueues of the batch (k4_device.h), owned

@@ -22,6 +22,7 @@
 // HBM traffic per unit: the two offset arrays, positions + frames of both sides once (52 bytes per entry), and the target
 // frames of a tile once more per further query segment (Infinity Cache).
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -37,16 +38,14 @@ constexpr unsigned long long HEAVY_HITS = 262144;   // hits of a tile beyond whi
 constexpr uint32_t HEAVY_MAX = 64;     // x extent of the split pass grid: its workgroups loop over the listed tiles
 constexpr uint32_t HEAVY_SPLIT = 8, HEAVY_QSPLIT = 8;   // ... over 8 shares of its target chunks x 8 shares of its query segments
 
+// One launch works off EVERY unit of a batch (grid.y = the batch's units that have seed hits to look for): the machine never
+// drains between units (a launch per unit left ~6 % of it idle in the tails of 4096 workgroups over 512 slots, and cost three
+// launches per unit).  A unit's own things come from a device table (FusedUnit, k4_device.h): its two seed indexes, its
+// number in the batch, and its region of the walk queue.
 struct FusedArgs {
-    IndexView T, Q;
+    const FusedUnit *units;
     ExtQueues q;
-    const uint32_t *tab;   // 4-base group table of the exact walk (global: 16 KiB, L1-resident)
-    uint32_t tlen, qlen;
-    uint32_t unit, same;
-    uint32_t tsoft;        // the target has a seed-validity plane of its own (soft-masked bases): no frame walks
     int xdrop, hspthresh, transitions;
-    uint32_t heavy_base;   // heavy pass: first listed tile of this launch
-    uint32_t heavy_pass;   // 0: every tile but the heavy ones (they are listed); 1: the listed tiles, each split over gridDim.y workgroups
     uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on
 };
 
@@ -165,6 +164,9 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
 
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // first pass: grid (tiles, units); split pass: grid (HEAVY_MAX x units, target shares, query shares)
+    const uint32_t ai = HEAVY ? blockIdx.x / HEAVY_MAX : blockIdx.y;
+    const FusedUnit U = A.units[ai];   // by value: wave-uniform registers for the whole kernel, not a reload through the pointer at every use
     uint32_t *sD = sD_all + wv * DQ;
     uint2 *s_walk = s_walk_all + wv * 64;
     uint32_t n_walk = 0;
@@ -174,15 +176,15 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long b = 0;
         const uint32_t shard = blockIdx.x & 7u;
-        if (lane == 0) b = atomicAdd(&A.q.ctr->nwalk[shard], (unsigned long long)n);
+        if (lane == 0) b = atomicAdd(&A.q.nwalk_u[(size_t)ai * 8 + shard], (unsigned long long)n);
         b = __shfl(b, 0);
-        if (lane < n && b + lane < A.q.walk_cap) A.q.walkq[(size_t)shard * A.q.walk_cap + b + lane] = s_walk[lane];
+        if (lane < n && b + lane < U.walk_cap) A.q.walkq[U.walk_base + (size_t)shard * U.walk_cap + b + lane] = s_walk[lane];
         __builtin_amdgcn_wave_barrier();
     };
 
     // everything below returns for the whole workgroup at once (the conditions are uniform)
     auto do_tile = [&](const uint32_t tile) {
-        const uint32_t *toff = A.T.off + (size_t)tile * TILE_WORDS, *qoff = A.Q.off + (size_t)tile * TILE_WORDS;
+        const uint32_t *toff = U.T.off + (size_t)tile * TILE_WORDS, *qoff = U.Q.off + (size_t)tile * TILE_WORDS;
         const uint32_t t0 = toff[0], nT = toff[TILE_WORDS] - t0;
         const uint32_t q0 = qoff[0], nQ = qoff[TILE_WORDS] - q0;
         if (!nT || !nQ) return;   // tile_hits is zeroed per batch
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             }
             const unsigned long long tile_est = *s_total * (A.transitions ? (unsigned long long)(SEED_WEIGHT + 1) : 1ull);
             if (tile_est > HEAVY_HITS || nQ > 0xFFFFu) {   // (a tile of 65536 query entries and more: 52 segments for one workgroup)
-                if (threadIdx.x == 0) A.q.heavy[atomicAdd(&A.q.ctr->nheavy, 1ull)] = tile;   // at most NTILE entries
+                if (threadIdx.x == 0) A.q.heavy[(size_t)ai * NTILE + atomicAdd(&A.q.nheavy_u[ai], 1ull)] = tile;   // at most NTILE entries per unit
                 return;
             }
         }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             ro[i] = 0;
             if (k <= TILE_WORDS) ro[i] = (HEAVY ? qoff[k] : (k < TILE_WORDS ? (reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[k] : q0 + nQ)) - q0;
         }
-        const uint4 *tF0 = A.T.fr + t0, *tF1 = tF0 + A.T.fr_stride, *tF2 = tF1 + A.T.fr_stride;
+        const uint4 *tF0 = U.T.fr + t0, *tF1 = tF0 + U.T.fr_stride, *tF2 = tF1 + U.T.fr_stride;
         const uint32_t nchunks = (nT + TCH - 1) / TCH;
         // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
         const uint32_t ch_first = (HEAVY ? blockIdx.y * WAVES : 0u) + wv, ch_step = (HEAVY ? gridDim.y : 1u) * WAVES;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         uint32_t npos = 0;
         if (ch_first < nchunks) {
             const uint32_t e = ch_first * TCH + lane;
-            if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+            if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
         }
         unsigned long long hits_acc = 0;   // pairs this wavefront enumerates in this tile (wave-uniform): the tile's exact hit count
         const uint32_t qs_first = HEAVY ? blockIdx.z * QSEG : 0u, qs_step = (HEAVY ? gridDim.z : 1u) * QSEG;
@@ -260,12 +262,12 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 if (k <= TILE_WORDS) sQ[k] = (qoff_t)(min(max(ro[i], qs), qe) - qs);
             }
             {
-                const uint4 *s0 = A.Q.fr + q0 + qs, *s1 = s0 + A.Q.fr_stride, *s2 = s1 + A.Q.fr_stride;
+                const uint4 *s0 = U.Q.fr + q0 + qs, *s1 = s0 + U.Q.fr_stride, *s2 = s1 + U.Q.fr_stride;
                 for (uint32_t i = threadIdx.x; i < qn; i += THREADS) {
                     sQF[i] = s0[i];
                     sQF[QSEG + i] = s1[i];
                     sQF[2 * QSEG + i] = s2[i];
-                    sQN[i] = (uint8_t)(A.Q.pos[q0 + qs + i] >> 31);
+                    sQN[i] = (uint8_t)(U.Q.pos[q0 + qs + i] >> 31);
                 }
             }
             __syncthreads();
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     if (nx >= nchunks) nx = (qs + qs_step < nQ) ? ch_first : 0xFFFFFFFFu;
                     if (nx != 0xFFFFFFFFu && nx != ch) {
                         const uint32_t e = nx * TCH + lane;
-                        if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = A.T.pos[t0 + e]; }
+                        if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
                     }
                 }
                 const bool tvalid = lane < ne;
@@ -349,13 +351,13 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                             if (A.dbg & 2u) need = false;
                         }
                         uint32_t qp = 0;
-                        if (A.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
+                        if (U.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
                             if (valid) {
-                                qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
                                 if ((tpf & POS_MASK) == qp) need = false;
                             }
                         } else if (need) {
-                            qp = A.Q.pos[q0 + qs + qi] & POS_MASK;
+                            qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
                         }
                         const uint64_t m = __ballot(need);
                         if (m) {
@@ -369,15 +371,15 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 }
             }
         }
-        if (lane == 0 && hits_acc) atomicAdd(&A.q.tile_hits[(size_t)A.unit * NTILE + tile], hits_acc);
+        if (lane == 0 && hits_acc) atomicAdd(&A.q.tile_hits[(size_t)U.unit * NTILE + tile], hits_acc);
     };
 
     if (!HEAVY) {
         do_tile(blockIdx.x);
     } else {
-        const uint32_t nlist = (uint32_t)min((unsigned long long)NTILE, A.q.ctr->nheavy);
-        for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) {
-            do_tile(A.q.heavy[li]);
+        const uint32_t nlist = (uint32_t)min((unsigned long long)NTILE, A.q.nheavy_u[ai]);
+        for (uint32_t li = blockIdx.x % HEAVY_MAX; li < nlist; li += HEAVY_MAX) {
+            do_tile(A.q.heavy[(size_t)ai * NTILE + li]);
             __syncthreads();   // the next tile's offsets overwrite this one's
         }
     }
@@ -402,20 +404,17 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st) {
     hipLaunchKernelGGL(k34_sum_hits, dim3(nunits), dim3(256), 0, st, (const unsigned long long *)q.tile_hits, q.unit_hits);
 }
 
-// The split pass is launched with a fixed grid: its workgroups loop over the listed tiles, each cut over HEAVY_SPLIT
-// shares of its target chunks x HEAVY_QSPLIT shares of its query segments (4096 workgroups that exit at once when no tile
-// is listed: a few microseconds per unit)
-static const dim3 HEAVY_GRID(HEAVY_MAX, HEAVY_SPLIT, HEAVY_QSPLIT);
+// The split pass is launched with a fixed grid per unit: its workgroups loop over the tiles the first pass listed for their unit,
+// each cut over HEAVY_SPLIT shares of its target chunks x HEAVY_QSPLIT shares of its query segments (4096 workgroups per unit
+// that exit at once when no tile is listed: a few microseconds)
 constexpr uint32_t QSEG_FIRST = 1280, QSEG_HEAVY = 1024;
 
-int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
-                      hipStream_t st, uint32_t dbg) {
+// the heavy phase of a batch: `nactive` units (table d_units), both passes
+int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const mimeo_params *p, hipStream_t st, uint32_t dbg) {
+    if (!nactive) return 0;
     FusedArgs A;
-    A.T = w.ti; A.Q = w.qi; A.q = q; A.tab = tab;
-    A.tlen = w.d.T.len; A.qlen = w.d.Q.len; A.tsoft = w.d.T.svt != nullptr ? 1u : 0u;
-    A.unit = unit; A.same = w.d.same;
+    A.units = d_units; A.q = q;
     A.xdrop = p->xdrop; A.hspthresh = p->hspthresh; A.transitions = p->transitions;
-    A.heavy_pass = 0; A.heavy_base = 0;
     A.dbg = dbg;   // MIMEO_K34_DEBUG, read once per batch by the caller
     constexpr size_t smem_heavy = FusedCfg<512, QSEG_HEAVY, true>::SMEM, smem_first = FusedCfg<512, QSEG_FIRST, false>::SMEM;
     static std::once_flag attr_once;   // the library may be driven from any one thread at a time: still set exactly once
@@ -429,9 +428,14 @@ int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, cons
     });
     HIP_TRY(attr_err);
     // measured on a C4 unit (two segments per tile at 1280, three at 1216 and 1024): 1.44 / 1.51 / 1.54 ms for the heavy phase
-    hipLaunchKernelGGL((k34_scan_extend<512, QSEG_FIRST, false>), dim3(NTILE), dim3(512), smem_first, st, A);
-    A.heavy_pass = 1;
-    hipLaunchKernelGGL((k34_scan_extend<512, QSEG_HEAVY, true>), dim3(HEAVY_GRID), dim3(512), smem_heavy, st, A);
+    for (uint32_t u0 = 0; u0 < nactive; u0 += 32768u) {   // grid.y and grid.x limits
+        const uint32_t nu = std::min(32768u, nactive - u0);
+        A.units = d_units + u0;
+        FusedArgs B = A;
+        B.q.nwalk_u = q.nwalk_u + (size_t)u0 * 8; B.q.nheavy_u = q.nheavy_u + u0; B.q.heavy = q.heavy + (size_t)u0 * NTILE;
+        hipLaunchKernelGGL((k34_scan_extend<512, QSEG_FIRST, false>), dim3(NTILE, nu), dim3(512), smem_first, st, B);
+        hipLaunchKernelGGL((k34_scan_extend<512, QSEG_HEAVY, true>), dim3(HEAVY_MAX * nu, HEAVY_SPLIT, HEAVY_QSPLIT), dim3(512), smem_heavy, st, B);
+    }
     return 0;
 }
 

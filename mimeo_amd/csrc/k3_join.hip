@@ -201,7 +201,21 @@ int DeviceBuf::reserve(size_t bytes) {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
-    HIP_TRY(hipMalloc(&p, want));
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory && want > bytes + 4096) {   // no room for the slack: the bytes asked for will do
+        (void)hipGetLastError();
+        want = bytes + 4096;
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        char what[160];
+        snprintf(what, sizeof what, "hipMalloc of %.2f GiB (device memory free: %.2f of %.2f GiB)", (double)want / (1 << 30), (double)free_b / (1 << 30),
+                 (double)total_b / (1 << 30));
+        return hip_fail(e, what, __FILE__, __LINE__);
+    }
     cap = want;
     return 0;
 }

@@ -20,12 +20,8 @@ struct ExtCounters {
     // number mod 8, i.e. per XCD: region r = [r * cap, ...)): a same-address atomic serialises at ~13 ns and a C4 unit
     // makes ~10^4 flushes.  nfollow / nmed hold the totals once k4_compact has gathered the follower shards.
     unsigned long long nfollow8[8], nmed8[8];
-    unsigned long long nwalk[8];   // entries of the walk queue of the current unit (K34 -> k4_extend_hits on the queue), in eight
-                                   // shards (workgroup number mod 8, i.e. per XCD): 50 000 flushes per unit on ONE counter
-                                   // would serialise at ~13 ns each
-    unsigned long long nheavy;     // tiles of the current unit that K34's first pass left to its split pass
     unsigned long long nbigcand;   // candidates longer than ENT_LONG columns: their entropy is counted by the whole grid
-    unsigned long long nwalk_total, nwalk_over;  // ... summed over the batch; largest shard count that exceeded a shard's capacity
+    unsigned long long nwalk_total, nwalk_over;  // walk-queue entries of the batch; fullest shard of any unit, in 1/1024 of its capacity (> 1024: overflow)
     unsigned long long dbg[8];  // development (MIMEO_K34_DEBUG & 8): why the pre-filter passed a hit on
 };
 
@@ -47,8 +43,10 @@ struct ExtQueues {
     uint32_t *fprev;
     uint2 *medq, *longq;      // hits whose walk outlives the frame / LONG_WINDOWS windows
     uint32_t *medu, *longu;   // ... and their units
-    uint2 *walkq;             // hits of the current unit that the pre-filter of K34 could not dismiss
-    uint32_t *heavy;                // ... their numbers
+    uint2 *walkq;             // hits that the pre-filter of K34 could not dismiss: a region of eight shards per unit (FusedUnit)
+    unsigned long long *nwalk_u;    // ... entries per unit and shard (workgroup number mod 8, i.e. per XCD)
+    unsigned long long *nheavy_u;   // tiles per unit that K34's first pass left to its split pass
+    uint32_t *heavy;                // ... their numbers: NTILE slots per unit
     unsigned long long *bigcand;    // indices of the long candidates (ENT_BIGCAP) and their accumulators: 5 per candidate
     unsigned long long *bigacc;     // ... matched A / C / G / T columns, raw score
     unsigned long long *unit_hits;  // seed hits per unit (statistics)

@@ -126,11 +126,11 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
 // (k34_fused.hip); this one is kept so that two independent decompositions of the stage can be compared byte for
 // byte at full size (MIMEO_HEAVY=v1, tests/test_gpu_hsp.py).
 template <int VARIANT>
-__global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q,
-                                                              const uint2 *__restrict__ hits, uint64_t nhits,
-                                                              int xdrop, int hspthresh, int transitions,
-                                                              const uint32_t *__restrict__ group_tab, ExtQueues q, uint32_t unit,
-                                                              int skip_diag0, const unsigned long long *__restrict__ nhits_dev) {
+__device__ __forceinline__ void extend_hits_body(const StrandView &T, const StrandView &Q,
+                                                 const uint2 *__restrict__ hits, uint64_t nhits,
+                                                 int xdrop, int hspthresh, int transitions,
+                                                 const uint32_t *__restrict__ group_tab, const ExtQueues &q, uint32_t unit,
+                                                 int skip_diag0, const unsigned long long *__restrict__ nhits_dev) {
     constexpr bool FILTER = VARIANT == 5 || VARIANT == 9;
     constexpr int SCAP = 256;   // staged generic-walk hits / followers per wavefront: one same-address atomic per 256 records
     // nhits_dev: the hits are the walk queue of this unit, filled by K34 just before on the same stream: eight shards of
@@ -222,16 +222,35 @@ __global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, Str
     walk_batch(false, make_uint2(0, 0), true);  // flush the staged records
     if (!nhits_dev && blockIdx.x == 0 && threadIdx.x == 0) q.unit_hits[unit] = nhits;
 }
+// the hit array of ONE unit (A/B path: K3's join)
+template <int VARIANT>
+__global__ __launch_bounds__(FAST_THREADS) void k4_extend_hits(StrandView T, StrandView Q, const uint2 *__restrict__ hits, uint64_t nhits,
+                                                              int xdrop, int hspthresh, int transitions,
+                                                              const uint32_t *__restrict__ group_tab, ExtQueues q, uint32_t unit, int skip_diag0) {
+    extend_hits_body<VARIANT>(T, Q, hits, nhits, xdrop, hspthresh, transitions, group_tab, q, unit, skip_diag0, nullptr);
+}
+// the walk queues of ALL units of the batch in one launch (grid.y = unit): a unit's region holds eight shards of walk_cap
+// entries, filled by K34 just before on the same stream, the counts on the device
+template <int VARIANT>
+__global__ __launch_bounds__(FAST_THREADS) void k4_walk_batch(const FusedUnit *__restrict__ funits, int xdrop, int hspthresh, int transitions,
+                                                             const uint32_t *__restrict__ group_tab, ExtQueues q) {
+    const FusedUnit &U = funits[blockIdx.y];
+    extend_hits_body<VARIANT>(U.Tv, U.Qv, q.walkq + U.walk_base, U.walk_cap, xdrop, hspthresh, transitions, group_tab, q, U.unit, 0,
+                              q.nwalk_u + (size_t)blockIdx.y * 8);
+}
 
-// the walk queue of a unit has been worked off: empty it for the next unit, keep the statistics and the overflow mark
-__global__ void k4_queue_reset(ExtCounters *ctr, uint64_t cap) {
-    for (int r = 0; r < 8; r++) {
-        const unsigned long long n = ctr->nwalk[r];
-        ctr->nwalk_total += n;
-        if (n > cap) ctr->nwalk_over = max(ctr->nwalk_over, n);
-        ctr->nwalk[r] = 0;
+// the walk queues of the batch: total entries, and the fullest shard in 1/1024 of its capacity (> 1024: an overflow, the
+// batch is repeated with larger regions)
+__global__ __launch_bounds__(256) void k4_walk_summary(const FusedUnit *__restrict__ funits, uint32_t nactive, const unsigned long long *__restrict__ nwalk_u,
+                                                       ExtCounters *ctr) {
+    unsigned long long tot = 0, worst = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nactive * 8u; i += gridDim.x * 256) {
+        const unsigned long long n = nwalk_u[i], cap = funits[i >> 3].walk_cap;
+        tot += n;
+        worst = max(worst, cap ? (n * 1024ull + cap - 1) / cap : (n ? 1ull << 40 : 0ull));
     }
-    ctr->nheavy = 0;
+    for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o); worst = max(worst, (unsigned long long)__shfl_xor(worst, o)); }
+    if ((threadIdx.x & 63) == 0) { if (tot) atomicAdd(&ctr->nwalk_total, tot); if (worst) atomicMax(&ctr->nwalk_over, worst); }
 }
 
 // ---- long hits, one wavefront each ------------------------------------------------------------------------
@@ -615,13 +634,12 @@ const uint32_t *group_table_device() {
 }
 
 // fused heavy kernel (k34_fused.hip)
-int launch_fused_unit(const UnitWork &w, uint32_t unit, const ExtQueues &q, const mimeo_params *p, const uint32_t *tab,
-                      hipStream_t st, uint32_t dbg);
+int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const mimeo_params *p, hipStream_t st, uint32_t dbg);
 void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
     for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror})
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror, &funits, &nwalk_u})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -661,7 +679,7 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
 // (finish()): up to 41 bytes each on top.
 uint64_t ExtBatch::queue_bytes() const {
     const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
-    return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : cap_w_ * 8 * 8);
+    return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8);
 }
 uint64_t ExtBatch::held_bytes() const {
     uint64_t b = 0;
@@ -702,6 +720,11 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
         if (w.d.same) h_selfs_.push_back(u);
     }
     expect_hits_ = expect_hits;
+    {   // a batch can be cut in two when at least two of its units launch the heavy kernels (a mirror unit rides with its source)
+        uint32_t launching = 0;
+        for (uint32_t u = 0; u < nunits; u++) launching += (work[u].ti.n && work[u].qi.n) ? 1u : 0u;
+        splittable_ = launching > 1;
+    }
     mirror_dst_.clear();
     if (mirror_dst && std::any_of(mirror_dst->begin(), mirror_dst->end(), [](uint32_t m) { return m != NO_MIRROR; })) {
         if (mirror_dst->size() != nunits) { set_error("internal: mirror table of the wrong size"); return MIMEO_ERR_ARG; }
@@ -745,12 +768,26 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
     cap_m_ = (uint64_t)(expect_hits * 0.03 / 8 * 1.5 * boost_m / shrink) + (uint64_t)(1048576 / shrink) + 64;
     cap_l_ = (uint64_t)(expect_hits * 0.002 * boost_l / shrink) + (uint64_t)(1048576 / shrink) + 64;
     cap_c_ = (uint64_t)(expect_hits * 0.002 * boost_c / shrink) + (uint64_t)(1048576 / shrink) + 64;
-    // the walk queue holds the hits of ONE unit (K34 passes ~4 % of the hits of random sequence on), in eight shards
-    cap_w_ = (uint64_t)(max_unit_hits * 0.12 / 8 * 1.5 * boost_w / shrink) + (uint64_t)(1048576 / shrink) + 64;
+    // the walk queue: a region of eight shards per unit, sized from the unit's expected hits (K34 passes ~4 % of the hits of
+    // random sequence on)
+    (void)max_unit_hits;
+    walk_entries_ = 0;
+    walk_cap_u_.assign(nunits, 0);
+    for (uint32_t u = 0; u < nunits; u++) {
+        const UnitWork &w = work[u];
+        if (!w.ti.n || !w.qi.n) continue;
+        const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
+        walk_cap_u_[u] = (uint64_t)(e * 0.12 / 8 * 1.5 * boost_w / shrink) + (uint64_t)(16384 / shrink) + 64;
+        walk_entries_ += 8 * walk_cap_u_[u];
+    }
     {   // a batch whose queues cannot fit is cut in two by the caller before anything is allocated (a single unit is tried anyway)
         uint64_t budget = 0;
         if ((rc = queue_budget(*this, &budget))) return rc;
-        if (nunits > 1 && queue_bytes() > budget) return MIMEO_ERR_SPLIT;
+        if (getenv("MIMEO_TRACE"))
+            fprintf(stderr, "[trace] batch of %u units, %.3g expected hits: queues %.2f GiB of %.2f GiB budget (boosts f %.1f m %.1f l %.1f c %.1f w %.1f; caps f %llu m %llu l %llu c %llu walk entries %llu)\n", nunits, expect_hits,
+                    (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30), boost_f, boost_m, boost_l, boost_c, boost_w,
+                    (unsigned long long)cap_f_, (unsigned long long)cap_m_, (unsigned long long)cap_l_, (unsigned long long)cap_c_, (unsigned long long)walk_entries_);
+        if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;
     }
     if (!mirror_dst_.empty()) {
         if ((rc = mirror.reserve((size_t)nunits * 4 + 16))) return rc;
@@ -772,7 +809,7 @@ int ExtBatch::enqueue_heavy() {
     ExtQueues &q = *(ExtQueues *)q_;
     memset(&q, 0, sizeof q);
     q.ebits = ebits_; q.dbits = dbits_;
-    const uint64_t cap_f = cap_f_, cap_m = cap_m_, cap_l = cap_l_, cap_c = cap_c_, cap_w = cap_w_;
+    const uint64_t cap_f = cap_f_, cap_m = cap_m_, cap_l = cap_l_, cap_c = cap_c_;
     const bool v1 = v1_;
     const std::vector<UnitWork> &work = w_;
     const std::vector<uint32_t> &h_selfs = h_selfs_;
@@ -781,17 +818,16 @@ int ExtBatch::enqueue_heavy() {
         if ((rc = fkey.reserve(cap_f * 8 * 8)) || (rc = fprev.reserve(cap_f * 8 * 4)) || (rc = medq.reserve(cap_m * 8 * 8)) ||
             (rc = medu.reserve(cap_m * 8 * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
             (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp) * (mirror_dst_.empty() ? 1 : 2))) ||
-            (rc = hsp_unit.reserve(cap_c * 4 * (mirror_dst_.empty() ? 1 : 2))) || (rc = walkq.reserve(v1 ? 8 : cap_w * 8 * 8)))
-            return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
+            (rc = hsp_unit.reserve(cap_c * 4 * (mirror_dst_.empty() ? 1 : 2))) || (rc = walkq.reserve(v1 ? 8 : walk_entries_ * 8 + 8)))
+            return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
         q.ctr = (ExtCounters *)ctr.p;
         q.cand = (Cand *)cand.p; q.fkey = (uint64_t *)fkey.p; q.fprev = (uint32_t *)fprev.p;
         q.medq = (uint2 *)medq.p; q.medu = (uint32_t *)medu.p; q.longq = (uint2 *)longq.p; q.longu = (uint32_t *)longu.p;
-        q.heavy = (uint32_t *)heavy.p;
         q.bigcand = (unsigned long long *)bigcand.p; q.bigacc = (unsigned long long *)bigacc.p;
         q.unit_hits = (unsigned long long *)unit_hits.p;
         q.tile_hits = (unsigned long long *)tile_hits.p;
         q.walkq = (uint2 *)walkq.p;
-        q.cand_cap = cap_c; q.follow_cap = cap_f; q.med_cap = cap_m; q.long_cap = cap_l; q.walk_cap = cap_w;
+        q.cand_cap = cap_c; q.follow_cap = cap_f; q.med_cap = cap_m; q.long_cap = cap_l; q.walk_cap = 0;
         const UnitDesc *d_units = (const UnitDesc *)units.p;
         HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(ExtCounters), st));
         HIP_TRY(hipMemsetAsync(unit_hits.p, 0, (size_t)nunits * 8, st));
@@ -806,32 +842,64 @@ int ExtBatch::enqueue_heavy() {
                                p->xdrop, p->hspthresh, p->transitions);
             HIP_TRY(hipEventRecord(side_done, side));
         }
-        // ---- heavy phase: one launch per unit, back to back, nothing read back
-        for (uint32_t u = 0; u < nunits; u++) {
-            const UnitWork &w = work[u];
-            if (!w.ti.n || !w.qi.n) continue;
-            if (!v1) {
-                // K34, then the hits it could not dismiss (3-4 % on random sequence, most of them false alarms of its
-                // cheap filter) through the sharp filter and the exact walk of round 1's fast kernel, then the queue
-                // is empty again for the next unit: three stream-ordered launches, nothing read back
-                while (kev.size() < 2 * (size_t)(u + 1)) {   // an event pair per unit: the seed-scan kernel's own duration
+        // ---- heavy phase, nothing read back
+        if (!v1) {
+            // K34 over every unit of the batch in ONE launch (plus its split pass), then the hits it could not dismiss (3-4 % on
+            // random sequence, most of them false alarms of its cheap filter) through the sharp filter and the exact walk of
+            // round 1's fast kernel, again one launch for all units (grid.y = unit), then the walk-queue statistics
+            std::vector<FusedUnit> h_fu;
+            bool slim = true;
+            uint64_t base = 0;
+            for (uint32_t u = 0; u < nunits; u++) {
+                const UnitWork &w = work[u];
+                if (!w.ti.n || !w.qi.n) continue;
+                FusedUnit f;
+                memset(&f, 0, sizeof f);
+                f.T = w.ti; f.Q = w.qi; f.Tv = w.d.T; f.Qv = w.d.Q; f.unit = u; f.same = w.d.same;
+                f.walk_base = base; f.walk_cap = walk_cap_u_[u];
+                base += 8 * f.walk_cap;
+                slim = slim && !w.d.T.has_n && !w.d.Q.has_n;
+                h_fu.push_back(f);
+            }
+            const uint32_t nactive = (uint32_t)h_fu.size();
+            nactive_ = nactive;
+            if (nactive) {
+                h_funits_ = std::move(h_fu);   // a member: the copy below is asynchronous
+                // counters: 8 walk-queue shards per unit, then the split-pass tile counts
+                if ((rc = funits.reserve((size_t)nactive * sizeof(FusedUnit))) || (rc = nwalk_u.reserve((size_t)nactive * 9 * 8)) ||
+                    (rc = heavy.reserve((size_t)nactive * NTILE * 4)))
+                    return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
+                q.heavy = (uint32_t *)heavy.p;
+                q.nwalk_u = (unsigned long long *)nwalk_u.p;
+                q.nheavy_u = q.nwalk_u + (size_t)nactive * 8;
+                HIP_TRY(hipMemcpyAsync(funits.p, h_funits_.data(), (size_t)nactive * sizeof(FusedUnit), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemsetAsync(nwalk_u.p, 0, (size_t)nactive * 9 * 8, st));
+                while (kev.size() < 2) {   // an event pair around the seed-scan kernel (both passes)
                     hipEvent_t e;
                     HIP_TRY(hipEventCreate(&e));
                     kev.push_back(e);
                 }
-                HIP_TRY(hipEventRecord(kev[2 * u], st));
-                if ((rc = launch_fused_unit(w, u, q, p, tab, st, k34_dbg_))) return rc;
-                HIP_TRY(hipEventRecord(kev[2 * u + 1], st));
-                const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
-                const unsigned long long *d_n = q.ctr->nwalk;
-                const uint32_t qblocks = qw_blocks_;
-#define K4_QUEUE(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3(qblocks), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)q.walkq, q.walk_cap, \
-                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, 0, d_n)
-                if (slim) K4_QUEUE(9);
-                else K4_QUEUE(5);
-#undef K4_QUEUE
-                hipLaunchKernelGGL(k4_queue_reset, dim3(1), dim3(1), 0, st, q.ctr, q.walk_cap);
-            } else {
+                HIP_TRY(hipEventRecord(kev[0], st));
+                if ((rc = launch_fused_batch((const FusedUnit *)funits.p, nactive, q, p, st, k34_dbg_))) return rc;
+                HIP_TRY(hipEventRecord(kev[1], st));
+                for (uint32_t u0 = 0; u0 < nactive; u0 += 32768u) {
+                    const uint32_t nu = std::min(32768u, nactive - u0);
+                    ExtQueues qq = q;
+                    qq.nwalk_u = q.nwalk_u + (size_t)u0 * 8;
+                    const FusedUnit *fu = (const FusedUnit *)funits.p + u0;
+                    // a unit's queue is worked off by at most qw_blocks_ workgroups (their end-of-kernel flushes are same-address
+                    // atomics: more workgroups cost more than they bring), fewer when many small units share the launch
+                    const uint32_t qblocks = std::max(1u, std::min(qw_blocks_, (8192u + nu - 1) / nu));
+                    if (slim) hipLaunchKernelGGL(k4_walk_batch<9>, dim3(qblocks, nu), dim3(FAST_THREADS), 0, st, fu, p->xdrop, p->hspthresh, p->transitions, tab, qq);
+                    else hipLaunchKernelGGL(k4_walk_batch<5>, dim3(qblocks, nu), dim3(FAST_THREADS), 0, st, fu, p->xdrop, p->hspthresh, p->transitions, tab, qq);
+                }
+                hipLaunchKernelGGL(k4_walk_summary, dim3(std::min(256u, (nactive * 8u + 255u) / 256u)), dim3(256), 0, st, (const FusedUnit *)funits.p, nactive,
+                                   (const unsigned long long *)q.nwalk_u, q.ctr);
+            }
+        } else {
+            for (uint32_t u = 0; u < nunits; u++) {
+                const UnitWork &w = work[u];
+                if (!w.ti.n || !w.qi.n) continue;
                 // A/B path: materialise the hits (exact count: one round trip per unit), then the round-1 fast kernel
                 uint64_t nh = 0;
                 if ((rc = join_hits(jc, w.ti, w.qi, p->transitions, hits, &nh, nullptr))) return rc;
@@ -840,7 +908,7 @@ int ExtBatch::enqueue_heavy() {
                 const int variant = k4_variant_;
                 const bool slim = !w.d.T.has_n && !w.d.Q.has_n;
 #define K4_LAUNCH(V) hipLaunchKernelGGL(k4_extend_hits<V>, dim3((uint32_t)nb), dim3(FAST_THREADS), 0, st, w.d.T, w.d.Q, (const uint2 *)hits.p, nh, \
-                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, (int)w.d.same, (const unsigned long long *)nullptr)
+                           p->xdrop, p->hspthresh, p->transitions, tab, q, u, (int)w.d.same)
                 if (variant == 1) K4_LAUNCH(1);
                 else if (variant == 5 || !slim) K4_LAUNCH(5);
                 else K4_LAUNCH(9);
@@ -874,7 +942,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
     uint64_t nf_total = 0, nm_total = 0;
     float ms_heavy = 0, ms_tails = 0, ms_walk = 0, ms_k34 = 0;
     for (int attempt = 0;; attempt++) {
-        uint64_t &cap_f = cap_f_, &cap_m = cap_m_, &cap_l = cap_l_, &cap_c = cap_c_, &cap_w = cap_w_;
+        uint64_t &cap_f = cap_f_, &cap_m = cap_m_, &cap_l = cap_l_, &cap_c = cap_c_;
         HIP_TRY(hipStreamWaitEvent(st, ev[1], 0));   // the heavy phase may have run on another stream
         // ---- tails, once per batch
         HIP_TRY(hipEventRecord(ev[3], st));
@@ -892,11 +960,11 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             maxm = std::max<uint64_t>(maxm, c.nmed8[r]);
         }
         nf_total = nf; nm_total = nm;
-        bool over = maxf > cap_f || maxm > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > cap_w;
+        bool over = maxf > cap_f || maxm > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > 1024;
         if (!over && nf) {
             if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
                 (rc = segs.reserve(nf * 8)) || (rc = bigseg.reserve(nf * 8)))
-                return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
+                return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
             size_t t1 = 0, t2 = 0;
             // the eight shards gathered into fkey2 / fprev2; the sort writes back into the (now free) shard area
             hipLaunchKernelGGL(k4_compact_followers, dim3(1024), dim3(256), 0, st, q, (uint64_t *)fkey2.p, (uint32_t *)fprev2.p);
@@ -904,7 +972,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
                                               (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             rocprim::counting_iterator<uint64_t> iota(0);
             HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)flags.p, (uint64_t *)segs.p, (uint64_t *)nsel.p, (size_t)nf, st));
-            if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc == MIMEO_ERR_NOMEM && nunits > 1 ? MIMEO_ERR_SPLIT : rc;
+            if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
             HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
                                               (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st, (const uint64_t *)fkey.p,
@@ -944,13 +1012,11 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             ms_heavy += a;
             ms_tails += b;
             ms_walk += w;
-            if (!v1)
-                for (uint32_t u = 0; u < nunits; u++)
-                    if (work[u].ti.n && work[u].qi.n) {
-                        float t = 0;
-                        HIP_TRY(hipEventElapsedTime(&t, kev[2 * u], kev[2 * u + 1]));
-                        ms_k34 += t;
-                    }
+            if (!v1 && nactive_) {
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, kev[0], kev[1]));
+                ms_k34 += t;
+            }
             break;
         }
         if (attempt >= 2) { set_error("extension queues overflowed twice in a row"); return MIMEO_ERR_LIMIT; }
@@ -959,7 +1025,11 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         cap_m = std::max<uint64_t>(cap_m, maxm + maxm / 2 + 1024);
         cap_l = std::max<uint64_t>(cap_l, c.nlong + c.nlong / 2 + 1024);
         cap_c = std::max<uint64_t>(cap_c, 2 * c.ncand + 65536);
-        cap_w = std::max<uint64_t>(cap_w, c.nwalk_over + c.nwalk_over / 4 + 1024);
+        if (c.nwalk_over > 1024) {   // every unit's walk-queue region grows by what the fullest shard lacked, and a quarter
+            const double grow = 1.25 * (double)c.nwalk_over / 1024.0;
+            walk_entries_ = 0;
+            for (auto &w : walk_cap_u_) { if (w) w = (uint64_t)((double)w * grow) + 1024; walk_entries_ += 8 * w; }
+        }   // (boost_w learns from the batch's real share of walked hits at the end of finish(), whatever the capacities were)
         if (stats) stats->reruns++;
         // what this batch showed goes into the sizing of the next ones whatever happens to it now
         if (expect_hits > 1e6) {
@@ -969,7 +1039,10 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         {
             uint64_t budget = 0;
             if ((rc = queue_budget(*this, &budget))) return rc;
-            if (nunits > 1 && queue_bytes() > budget) return MIMEO_ERR_SPLIT;   // the caller cuts the batch in two
+            if (getenv("MIMEO_TRACE"))
+                fprintf(stderr, "[trace] overflow of a batch of %u units: followers %llu (fullest shard), generic %llu, long %llu, cand %llu, walk %.2fx; queues would take %.2f GiB of %.2f GiB\n",
+                        nunits, (unsigned long long)maxf, (unsigned long long)maxm, c.nlong, c.ncand, (double)c.nwalk_over / 1024.0, (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30));
+            if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;   // the caller cuts the batch in two
         }
         if ((rc = enqueue_heavy())) return rc;   // the batch again, on this stream, with room
     }
@@ -1003,8 +1076,9 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             stats->scan_bytes_algorithmic += (Lq + 3) / 4 + (Lq > 18 ? 8ull * 13ull * (Lq - 18) : 0) + 12ull * H;
             // compulsory traffic of the fused kernel: both offset arrays, positions and frames of both sides once
             stats->scan_bytes_kernel += 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 52ull * ((uint64_t)work[u].ti.n + work[u].qi.n);
-            if (work[u].ti.n && work[u].qi.n) stats->heavy_launches++;
+            if (work[u].ti.n && work[u].qi.n) stats->heavy_launches++;   // units: the seed-scan kernel takes a batch of them per launch
         }
+        if (!v1 && nactive_) stats->heavy_kernel_launches++;
         stats->walked += c.nwalked;
         stats->walk_queue += c.nwalk_total;
         stats->ms_walk += ms_walk;

@@ -337,9 +337,10 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
         uint64_t nh = 0;
         rc = g_ext.run(work, p, &nh, &est, &mirror_dst);
         if (rc == MIMEO_ERR_SPLIT) {   // the queues of this batch do not fit: smaller batches from here on
+            if (b1 - b0 <= 1) { set_error("internal: a batch of one unit was refused"); rc = MIMEO_ERR_NOMEM; break; }
             rc = 0;
             max_hits = std::max(1.0, hits / 2);
-            if (b1 - b0 > 1) max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
+            max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
             continue;
         }
         if (rc) break;
@@ -563,9 +564,10 @@ int align_units_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
             uint64_t nh = 0;
             rc = g_ext.run(work, p, &nh, &est, &mirror_dst);
             if (rc == MIMEO_ERR_SPLIT) {   // the queues of this batch do not fit beside the indexes: smaller batches from here on
+                if (b1 - b0 <= 1) { set_error("internal: a batch of one unit was refused"); rc = MIMEO_ERR_NOMEM; break; }
                 rc = 0;
                 max_hits = std::max(1.0, hits / 2);
-                if (b1 - b0 > 1) max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
+                max_units = std::max<size_t>(1, std::min(max_units, work.size() / 2));
                 continue;
             }
             if (rc) break;
@@ -650,6 +652,7 @@ int align_units_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     g_stats.scan_bytes_algorithmic = est.scan_bytes_algorithmic;
     g_stats.scan_bytes_kernel = est.scan_bytes_kernel;
     g_stats.scan_launches = est.heavy_launches;
+    g_stats.scan_kernel_launches = est.heavy_kernel_launches;
     g_stats.walked_hits = est.walked;
     g_stats.followers = est.followers;
     g_stats.queue_reruns = est.reruns;

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Params) == 64
     assert _ffi.SEED_HIT.itemsize == 8 and _ffi.HSP.itemsize == 32
     assert _ffi.ALIGNMENT.itemsize == 48 and _ffi.INTERVAL.itemsize == 12
-    assert C.sizeof(_ffi.Stats) == 8 * 8 + 7 * 8 + 8 + 8 + 6 * 8
+    assert C.sizeof(_ffi.Stats) == 8 * 8 + 7 * 8 + 8 + 8 + 7 * 8
 
 
 def test_no_cpu_fallback_without_device():
