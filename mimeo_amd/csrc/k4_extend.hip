@@ -681,6 +681,12 @@ uint64_t ExtBatch::queue_bytes() const {
     const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
     return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8);
 }
+// the big queue buffers back to the device pool (a batch that was cut in two, or buffers grossly larger than the next batch
+// needs: every buffer is an allocation of its own, so room held by one cannot serve another that must grow)
+void ExtBatch::release_queues() {
+    for (DeviceBuf *d : {&cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp, &bigseg, &hsps, &hsp_unit})
+        d->release();
+}
 uint64_t ExtBatch::held_bytes() const {
     uint64_t b = 0;
     for (const DeviceBuf *d : {&cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp, &bigseg, &hsps, &hsp_unit})
@@ -787,7 +793,8 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
             fprintf(stderr, "[trace] batch of %u units, %.3g expected hits: queues %.2f GiB of %.2f GiB budget (boosts f %.1f m %.1f l %.1f c %.1f w %.1f; caps f %llu m %llu l %llu c %llu walk entries %llu)\n", nunits, expect_hits,
                     (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30), boost_f, boost_m, boost_l, boost_c, boost_w,
                     (unsigned long long)cap_f_, (unsigned long long)cap_m_, (unsigned long long)cap_l_, (unsigned long long)cap_c_, (unsigned long long)walk_entries_);
-        if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;
+        if (splittable_ && queue_bytes() > budget) { release_queues(); return MIMEO_ERR_SPLIT; }
+        if (held_bytes() > 2 * queue_bytes() + (4ull << 30)) release_queues();   // sized for a much larger batch: give the room back
     }
     if (!mirror_dst_.empty()) {
         if ((rc = mirror.reserve((size_t)nunits * 4 + 16))) return rc;
@@ -961,6 +968,12 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         }
         nf_total = nf; nm_total = nm;
         bool over = maxf > cap_f || maxm > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > 1024;
+        if (!over && nf && splittable_) {   // the sort's second buffers, flags, segment lists and rocPRIM's scratch: ~41 bytes per follower
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t have = (uint64_t)free_b + fkey2.cap + fprev2.cap + flags.cap + segs.cap + bigseg.cap + tmp.cap;
+            if (nf * 41ull + (1ull << 30) > have) { release_queues(); return MIMEO_ERR_SPLIT; }
+        }
         if (!over && nf) {
             if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
                 (rc = segs.reserve(nf * 8)) || (rc = bigseg.reserve(nf * 8)))
@@ -1019,7 +1032,8 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             }
             break;
         }
-        if (attempt >= 2) { set_error("extension queues overflowed twice in a row"); return MIMEO_ERR_LIMIT; }
+        // (a walk queue that overflowed hides followers and candidates of the hits it dropped: the repeat may overflow those in turn)
+        if (attempt >= 4) { set_error("extension queues overflowed four times in a row"); return MIMEO_ERR_LIMIT; }
         // room for what the counters saw, and half as much again: the repeated tails may add candidates of their own
         cap_f = std::max<uint64_t>(cap_f, maxf + maxf / 2 + 1024);
         cap_m = std::max<uint64_t>(cap_m, maxm + maxm / 2 + 1024);
@@ -1035,6 +1049,9 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         if (expect_hits > 1e6) {
             boost_f = std::min(4096.0, std::max(boost_f, 1.5 * (double)(8 * maxf) / (0.02 * expect_hits)));
             boost_m = std::min(4096.0, std::max(boost_m, 1.5 * (double)(8 * maxm) / (0.03 * expect_hits)));
+            boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * expect_hits)));
+            boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * expect_hits)));
+            boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * expect_hits)));   // the counters count beyond the capacities
         }
         {
             uint64_t budget = 0;
@@ -1042,7 +1059,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             if (getenv("MIMEO_TRACE"))
                 fprintf(stderr, "[trace] overflow of a batch of %u units: followers %llu (fullest shard), generic %llu, long %llu, cand %llu, walk %.2fx; queues would take %.2f GiB of %.2f GiB\n",
                         nunits, (unsigned long long)maxf, (unsigned long long)maxm, c.nlong, c.ncand, (double)c.nwalk_over / 1024.0, (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30));
-            if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;   // the caller cuts the batch in two
+            if (splittable_ && queue_bytes() > budget) { release_queues(); return MIMEO_ERR_SPLIT; }   // the caller cuts the batch in two
         }
         if ((rc = enqueue_heavy())) return rc;   // the batch again, on this stream, with room
     }

@@ -29,7 +29,7 @@ for f in sorted(glob.glob(sys.argv[1] + '/pass*.csv')):
         k = r['Kernel_Name']
         if 'k34_scan' in k:
             name = 'k34_scan_extend (split pass)' if 'true>' in k else 'k34_scan_extend (first pass)'
-        elif 'k4_extend_hits' in k: name = 'k4_extend_hits (walk queue)'
+        elif 'k4_walk_batch' in k or 'k4_extend_hits' in k: name = 'k4_walk_batch (walk queue)'
         elif 'k4_extend_generic' in k: name = 'k4_extend_generic'
         elif 'k4_entropy' in k and 'big' not in k: name = 'k4_entropy'
         else: continue

@@ -22,7 +22,7 @@ import csv, sys, collections, json
 acc = collections.defaultdict(float); cnt = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name']
-    name = 'k34_scan_extend' if ('k34_scan' in k and 'true>' not in k) else ('k4_extend_hits (walk queue)' if 'k4_extend_hits' in k else None)
+    name = 'k34_scan_extend' if ('k34_scan' in k and 'true>' not in k) else ('k4_walk_batch (walk queue)' if ('k4_walk_batch' in k or 'k4_extend_hits' in k) else None)
     if name is None or r['Counter_Name'] != sys.argv[3]: continue
     acc[name] += float(r['Counter_Value']); cnt[name] += 1
 print('"%s_%s_KB_per_launch": %s' % (sys.argv[2], sys.argv[3], json.dumps({k: round(v / cnt[k], 1) for k, v in acc.items()})), end='')

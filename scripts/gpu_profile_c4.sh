@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the default bench (C4 rows); summary -> gpurun_out/<tag>_kernel_stats.csv
-tag=${1:-r02_bench_c4_rows}
+tag=${1:-r03_bench_c4_rows}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_tmp
