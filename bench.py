@@ -25,7 +25,7 @@ whole job takes at that rate).
 Job mode (workloads c2, small, c3, c5, ...: the other BASELINE configs, development aids): a step is the
 whole job, pairs sharded over ranks, "scaling" "strong" (the round-1 bench line for C2 is kept in profiles/).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4small|c4job|c2|small|c3|c5|c3small|c5small] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4small|c4job|c2|small|c3|c5|c3small|c5small|c5mid] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -50,6 +50,7 @@ WORKLOADS = {
     'c3small': ('x', 201, 202, 8_000_000, 4, 80, 5, 'job'),
     'c5': ('map', 1001, 1002, 1_000_000_000, 100, 98, 0, 'job'),
     'c5small': ('map', 1001, 1002, 8_000_000, 4, 98, 0, 'job'),
+    'c5mid': ('map', 1001, 1002, 40_000_000, 4, 98, 0, 'job'),   # 16 pairs of C5's own 10 Mbp scaffolds: a profile-sized piece of C5
 }
 MIN_LEN = 100
 

@@ -148,8 +148,10 @@ int build_index(const StrandView &s, SeedIndex &out, float *ms, uint32_t p0 = 0,
 struct DeviceBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool view = false;     // a slice of an arena (another DeviceBuf owns the memory): never freed or grown through this handle
     int reserve(size_t bytes);
     void release();
+    void set_view(void *ptr, size_t bytes) { p = ptr; cap = bytes; view = true; }
 };
 struct JoinTiming { float ms_count = 0, ms_fill = 0; };
 // per-lane work state of K3 (a lane = one host thread + one stream working through units)
@@ -223,12 +225,15 @@ struct ExtBatch {
     std::vector<UnitDesc> h_units_;
     std::vector<FusedUnit> h_funits_;
     DeviceBuf mirror;     // mirror_dst_ on the device + one counter
+    // hipMalloc / hipFree of tens of GB cost seconds (C5 at full size spent 80 % of its wall time there): the queues of a batch are
+    // slices of ONE allocation that only ever grows (arena_q, carved per batch), the follower sort's buffers of another (arena_s)
+    DeviceBuf arena_q, arena_s;
     DeviceBuf funits, nwalk_u;   // per-unit table of the heavy kernels (FusedUnit); walk-queue counters per unit and shard + split-pass tile counts
     std::vector<uint64_t> walk_cap_u_;   // walk-queue capacity per unit and shard
     uint64_t walk_entries_ = 0;          // ... all regions together
     uint32_t nactive_ = 0;               // units of the batch that launch the heavy kernels
     uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0;
-    double expect_hits_ = 0;
+    double expect_hits_ = 0, shrink_ = 1.0;
     uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;
     bool v1_ = false, started_ = false, k4_stats_ = false, splittable_ = false;
     uint32_t k34_dbg_ = 0, qw_blocks_ = 256;

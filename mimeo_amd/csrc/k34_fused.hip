@@ -125,6 +125,27 @@ __device__ __forceinline__ bool pair_needs_walk(const uint4 t0, const uint4 t1, 
     return !(L.stop && R.stop && L.ub + R.ub < hspthresh && veto == 0);
 }
 
+// Split pass only (the tiles microsatellites and high-copy repeats fill): is this pair an INTERIOR member of a run of consecutive
+// seed hits of its diagonal — exact seed hits one and two positions back and one ahead (k4_device.h, "runs of consecutive seed
+// hits")?  Such a hit leaves no record anywhere, so it is dropped here, before the pre-filter and the walk queue.  The three
+// 19-windows start at frame bits 107, 108 and 110 (the hit's own at 109): words 3 and 4 of the planes.  Exact for frames
+// without N of a unit whose target has no soft-masked bases, with the windows inside both scaffolds (the caller checks):
+// the same predicate seed_hit_at() evaluates on the planes for the members that do reach the walk kernel.
+__device__ __forceinline__ bool run_interior(const uint4 t0, const uint4 t1, const uint4 t2, const uint4 q0, const uint4 q1, const uint4 q2,
+                                             int transitions) {
+    // planes: lo = {0.x 0.y 0.z 0.w 1.x 1.y}, hi = {1.z 1.w 2.x 2.y 2.z 2.w}
+    const uint32_t dl3 = t0.w ^ q0.w, dl4 = t1.x ^ q1.x;
+    const uint32_t n3 = dl3 | (t2.y ^ q2.y), n4 = dl4 | (t2.z ^ q2.z);
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int off = k == 0 ? 11 : (k == 1 ? 12 : 14);   // frame bit of the window start - 96
+        const uint32_t wn = __builtin_amdgcn_alignbit(n4, n3, off) & CARE19, wd = __builtin_amdgcn_alignbit(dl4, dl3, off) & CARE19;
+        all = all && (transitions ? (wd == 0u && __popc(wn) <= 1) : (wn == 0u));
+    }
+    return all;
+}
+
 __device__ __forceinline__ uint4 bperm4(uint32_t src_lane, const uint4 v) {
     const int a = (int)(src_lane << 2);
     return make_uint4((uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.x), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.y),
@@ -175,7 +196,8 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
     auto flush_walk = [&](uint32_t n) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long b = 0;
-        const uint32_t shard = blockIdx.x & 7u;
+        // (split pass: the 64 workgroups that share a tile have one blockIdx.x — spread them, or a microsatellite tile fills one shard)
+        const uint32_t shard = (HEAVY ? blockIdx.x + blockIdx.y + blockIdx.z : blockIdx.x) & 7u;
         if (lane == 0) b = atomicAdd(&A.q.nwalk_u[(size_t)ai * 8 + shard], (unsigned long long)n);
         b = __shfl(b, 0);
         if (lane < n && b + lane < U.walk_cap) A.q.walkq[U.walk_base + (size_t)shard * U.walk_cap + b + lane] = s_walk[lane];
@@ -344,13 +366,27 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                         const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
                         const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
                         bool need = false;
-                        if (valid) {
-                            if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
-                            else need = ((tpf >> 31) | sQN[qi]) != 0 ||
-                                        pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
-                            if (A.dbg & 2u) need = false;
-                        }
                         uint32_t qp = 0;
+                        bool live = valid;   // still to be looked at by the pre-filter
+                        if (HEAVY && !(A.dbg & 16u)) {
+                            // interior members of runs of consecutive seed hits leave no record: out, before the filter (a microsatellite
+                            // tile is nearly all of them: whole rounds skip the filter)
+                            bool inner = false;
+                            if (valid && ((tpf >> 31) | sQN[qi]) == 0 && U.Tv.svt == nullptr && run_interior(ta, tb, tc, qa, qb, qc, A.transitions)) {
+                                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
+                                const uint32_t tp = tpf & POS_MASK;
+                                inner = tp >= 2u && qp >= 2u && tp + 1u + SEED_LEN <= U.Tv.len && qp + 1u + SEED_LEN <= U.Qv.len;
+                            }
+                            live = valid && !inner;
+                        }
+                        if (__ballot(live)) {
+                            if (live) {
+                                if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
+                                else need = ((tpf >> 31) | sQN[qi]) != 0 ||
+                                            pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
+                                if (A.dbg & 2u) need = false;
+                            }
+                        }
                         if (U.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
                             if (valid) {
                                 qp = U.Q.pos[q0 + qs + qi] & POS_MASK;

@@ -12,6 +12,8 @@
 // Launches: k3_join_count (per-tile hit counts) -> k3_tile_scan -> k3_join_fill.  The fill kernel
 // places hits with a workgroup prefix sum, so the output order is deterministic:
 // (key, target position, neighbour, query position).
+#include <chrono>
+
 #include "common.h"
 
 namespace mimeo {
@@ -195,8 +197,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k3_join_fill(const uint32_t *__r
     }
 }
 
+double g_alloc_ms = 0;   // host time spent in hipMalloc / hipFree of work buffers (MIMEO_TRACE prints it per call)
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 int DeviceBuf::reserve(size_t bytes) {
     if (bytes <= cap) return 0;
+    if (view) { set_error("internal: a slice of an arena cannot grow"); return MIMEO_ERR_ARG; }
+    AllocTimer timer;
     if (p) HIP_TRY(hipFree(p));
     p = nullptr;
     cap = 0;
@@ -220,6 +229,8 @@ int DeviceBuf::reserve(size_t bytes) {
     return 0;
 }
 void DeviceBuf::release() {
+    if (view) { p = nullptr; cap = 0; view = false; return; }
+    AllocTimer timer;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;

@@ -75,6 +75,19 @@ __device__ __forceinline__ int32_t key_diag(const ExtQueues &q, uint64_t k, uint
     return (int32_t)(uint32_t)((k >> q.ebits) & ((1ull << q.dbits) - 1ull)) - (int32_t)qlen;
 }
 
+// ---- runs of consecutive seed hits -------------------------------------------------------------------------------
+// Inside real similarity — and wholesale inside microsatellites, where two arrays of one motif are a rectangle of seed hits —
+// a diagonal carries seed hits at CONSECUTIVE positions: e, e + 1, e + 2, ...  Every one of them but the first has its
+// left neighbour as nearest earlier seed hit (the left walk reaches the boundary one step back whatever the bases: no
+// single column can trip the x-drop), i.e. is a follower with predecessor end e - 1, and a C5 unit has 3e8 of those to sort.
+// A run is therefore recorded by its two ends only: the first of these followers as an ordinary follower record
+// (seed end s, predecessor s - 1), the last one as a RUN_END record (seed end t, predecessor field RUN_END): between two
+// such records EVERY position s + 1 .. t is a follower naming its left neighbour.  A member decides what it is from
+// three exact seed tests on its own diagonal: the hits one back (it is such a follower at all), two back (it is not the
+// first) and one ahead (it is not the last); interior members leave no record.  The segment flags and the two resolution
+// kernels read a RUN_END record as the range it closes.
+constexpr uint32_t RUN_END = 0xFFFFFFFFu;
+
 // is there a seed hit whose 19-window starts at target position p (query p - d)?
 __device__ __forceinline__ bool seed_hit_at(const StrandView &T, const StrandView &Q, int32_t p, int32_t d,
                                             int transitions) {
@@ -486,6 +499,11 @@ __device__ __forceinline__ void walk_hit(const uint32_t *__restrict__ tab, const
         q_fol = true;
         r_fk = ((uint64_t)(uint32_t)(d + (int32_t)Q.len) << 32) | (uint32_t)et;  // the batch key is composed when the record is flushed
         r_fp = (uint32_t)et - L.found_step;
+        if (L.found_step == 1) {   // a member of a run of consecutive seed hits: only the run's ends leave records
+            const bool two_back = seed_hit_at(T, Q, (int32_t)h.x - 2, d, transitions), ahead = seed_hit_at(T, Q, (int32_t)h.x + 1, d, transitions);
+            if (two_back && ahead) q_fol = false;     // interior
+            else if (two_back) r_fp = RUN_END;        // the last one (and not the first)
+        }
     } else {
         // ---- right walk: two windows from the frame (frame bit of the seed end = 64 + bt + 19)
         WalkState R{0, 0, 0, 0, false, false, 0};

@@ -289,7 +289,8 @@ __global__ void k4_segment_flags(const uint64_t *__restrict__ key, const uint32_
     bool start = true;
     if (i > 0) {
         uint64_t a = key[i - 1], b = key[i];
-        start = key_unit_diag(q, a) != key_unit_diag(q, b) || key_end(q, a) != prev[i];
+        // a RUN_END record closes the run its predecessor in the list opened (or continued): never a segment start
+        start = prev[i] != RUN_END && (key_unit_diag(q, a) != key_unit_diag(q, b) || key_end(q, a) != prev[i]);
     }
     flag[i] = start ? 1 : 0;
 }
@@ -326,17 +327,21 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_small(const UnitDesc *
         big = !lane_walk(tab, T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop, H);
         uint32_t reach = (uint32_t)het + H.bk;
         for (uint64_t i = beg; i < end && !big; i++) {
-            const uint32_t et = key_end(q, key[i]);
-            if (et <= reach) continue;  // inside the region the previous extension reached
-            const int32_t eq = (int32_t)et - d;
-            WalkState L{0, 0, 0, 0, false, false, 0}, R{0, 0, 0, 0, false, false, 0};
-            if (!lane_walk(tab, T, Q, (int32_t)et, d, -1, (uint32_t)min((int32_t)et, eq), xdrop, L) ||
-                !lane_walk(tab, T, Q, (int32_t)et, d, +1, min(T.len - et, Q.len - (uint32_t)eq), xdrop, R)) {
-                big = true;
-                break;
+            // the positions this record stands for: its own seed end, or — a RUN_END record — every one behind the record before it
+            const uint32_t hi = key_end(q, key[i]);
+            const uint32_t lo = prev[i] == RUN_END ? key_end(q, key[i - 1]) + 1u : hi;
+            for (uint32_t et = max(lo, reach + 1u); et <= hi && !big; et = reach + 1u) {   // the next one beyond the region the previous extension reached
+                const int32_t eq = (int32_t)et - d;
+                WalkState L{0, 0, 0, 0, false, false, 0}, R{0, 0, 0, 0, false, false, 0};
+                if (nout == SMALL_SEG ||
+                    !lane_walk(tab, T, Q, (int32_t)et, d, -1, (uint32_t)min((int32_t)et, eq), xdrop, L) ||
+                    !lane_walk(tab, T, Q, (int32_t)et, d, +1, min(T.len - et, Q.len - (uint32_t)eq), xdrop, R)) {
+                    big = true;
+                    break;
+                }
+                if (L.best + R.best >= hspthresh) out[nout++] = Cand{et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best, unit};
+                reach = et + R.bk;
             }
-            if (L.best + R.best >= hspthresh) out[nout++] = Cand{et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, L.best + R.best, unit};
-            reach = et + R.bk;
         }
     }
     if (big) {  // nothing has been emitted for this segment yet: the wavefront kernel redoes it
@@ -371,7 +376,8 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(const UnitDes
     uint32_t reach = (uint32_t)het + R.bsteps;
     uint64_t i = beg;
     while (i < end) {
-        // first member at or after i whose seed end lies beyond reach (members are sorted by seed end)
+        // first record at or after i that reaches beyond `reach` (records are sorted by seed end; a RUN_END record stands for
+        // every position behind the record before it up to its own)
         uint64_t lo = i, hi = end;
         while (lo < hi) {
             uint64_t mid = (lo + hi) >> 1;
@@ -380,11 +386,12 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(const UnitDes
         uint64_t nxt = lo;
         if (nxt >= end) break;
         uint32_t et = key_end(q, key[nxt]);
+        if (prev[nxt] == RUN_END) et = max(key_end(q, key[nxt - 1]) + 1u, reach + 1u);   // the first member of the run beyond the reach
         uint2 h = make_uint2(et - SEED_LEN, (uint32_t)((int32_t)et - d) - SEED_LEN);
         uint32_t rext = 0;
         wave_extend_emit(T, Q, h, xdrop, hspthresh, transitions, false, q, unit, &rext);
         reach = et + rext;
-        i = nxt + 1;
+        i = nxt;   // the same record again: a run may hold more members beyond the new reach (a plain record is passed by the search)
     }
     }
 }
@@ -639,7 +646,7 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
     for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror, &funits, &nwalk_u})
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror, &funits, &nwalk_u, &arena_q, &arena_s})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -681,18 +688,20 @@ uint64_t ExtBatch::queue_bytes() const {
     const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
     return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8);
 }
-// the big queue buffers back to the device pool (a batch that was cut in two, or buffers grossly larger than the next batch
-// needs: every buffer is an allocation of its own, so room held by one cannot serve another that must grow)
+// carve `bytes` (rounded up to 256) off an arena at *off
+static void *carve(const DeviceBuf &arena, size_t *off, size_t bytes) {
+    void *p = (char *)arena.p + *off;
+    *off += (bytes + 255) & ~(size_t)255;
+    return p;
+}
+// the arenas back to the device pool (mimeo_shutdown, or a call that ends in an allocation failure)
 void ExtBatch::release_queues() {
     for (DeviceBuf *d : {&cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp, &bigseg, &hsps, &hsp_unit})
-        d->release();
+        d->release();   // slices: nothing is freed here
+    arena_q.release();
+    arena_s.release();
 }
-uint64_t ExtBatch::held_bytes() const {
-    uint64_t b = 0;
-    for (const DeviceBuf *d : {&cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp, &bigseg, &hsps, &hsp_unit})
-        b += d->cap;
-    return b;
-}
+uint64_t ExtBatch::held_bytes() const { return arena_q.cap; }
 // free device memory plus what the batch's own buffers would give back, less a reserve for chain / gapped scratch
 static int queue_budget(const ExtBatch &b, uint64_t *budget) {
     size_t free_b = 0, total_b = 0;
@@ -767,6 +776,7 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
     // units) is repeated with room for everything the counters saw.  On random sequence 0.65 % of the hits
     // are followers, ~1 % outlive the frame and 1e-4 become candidates.
     const double shrink = getenv("MIMEO_QUEUE_SHRINK") ? atof(getenv("MIMEO_QUEUE_SHRINK")) : 1.0;  // tests: force the rerun
+    shrink_ = shrink > 0 ? shrink : 1.0;
     // `boost`: the largest excess over these shares that an earlier batch showed (a repeat-rich genome overflows the
     // first batch once, not every batch)
     // (followers and generic-walk hits: capacity PER SHARD, eight shards, with half as much again for their imbalance)
@@ -793,8 +803,7 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
             fprintf(stderr, "[trace] batch of %u units, %.3g expected hits: queues %.2f GiB of %.2f GiB budget (boosts f %.1f m %.1f l %.1f c %.1f w %.1f; caps f %llu m %llu l %llu c %llu walk entries %llu)\n", nunits, expect_hits,
                     (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30), boost_f, boost_m, boost_l, boost_c, boost_w,
                     (unsigned long long)cap_f_, (unsigned long long)cap_m_, (unsigned long long)cap_l_, (unsigned long long)cap_c_, (unsigned long long)walk_entries_);
-        if (splittable_ && queue_bytes() > budget) { release_queues(); return MIMEO_ERR_SPLIT; }
-        if (held_bytes() > 2 * queue_bytes() + (4ull << 30)) release_queues();   // sized for a much larger batch: give the room back
+        if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;
     }
     if (!mirror_dst_.empty()) {
         if ((rc = mirror.reserve((size_t)nunits * 4 + 16))) return rc;
@@ -822,11 +831,27 @@ int ExtBatch::enqueue_heavy() {
     const std::vector<uint32_t> &h_selfs = h_selfs_;
     int rc;
     {
-        if ((rc = fkey.reserve(cap_f * 8 * 8)) || (rc = fprev.reserve(cap_f * 8 * 4)) || (rc = medq.reserve(cap_m * 8 * 8)) ||
-            (rc = medu.reserve(cap_m * 8 * 4)) || (rc = longq.reserve(cap_l * 8)) || (rc = longu.reserve(cap_l * 4)) ||
-            (rc = cand.reserve(cap_c * sizeof(Cand))) || (rc = hsps.reserve(cap_c * sizeof(mimeo_hsp) * (mirror_dst_.empty() ? 1 : 2))) ||
-            (rc = hsp_unit.reserve(cap_c * 4 * (mirror_dst_.empty() ? 1 : 2))) || (rc = walkq.reserve(v1 ? 8 : walk_entries_ * 8 + 8)))
-            return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
+        {   // the queues of the batch: slices of one allocation (it grows when a batch needs more, with room to spare, and stays)
+            const size_t mf = mirror_dst_.empty() ? 1 : 2;
+            const size_t sz[10] = {cap_f * 8 * 8, cap_f * 8 * 4, cap_m * 8 * 8, cap_m * 8 * 4, cap_l * 8, cap_l * 4, cap_c * sizeof(Cand),
+                                   cap_c * sizeof(mimeo_hsp) * mf, cap_c * 4 * mf, v1 ? 8 : walk_entries_ * 8 + 8};
+            size_t total = 0;
+            for (size_t z : sz) total += (z + 255) & ~(size_t)255;
+            if (total > arena_q.cap) {
+                for (DeviceBuf *d : {&fkey, &fprev, &medq, &medu, &longq, &longu, &cand, &hsps, &hsp_unit, &walkq}) d->release();
+                // grow with room to spare when the device has it (the next overflow should not allocate again)
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                const size_t have = free_b + arena_q.cap;
+                size_t want = total + total / 2;
+                if (want + (8ull << 30) > have) want = total;
+                if ((rc = arena_q.reserve(want)) && want > total) rc = arena_q.reserve(total);
+                if (rc) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
+            }
+            size_t off = 0;
+            DeviceBuf *bufs[10] = {&fkey, &fprev, &medq, &medu, &longq, &longu, &cand, &hsps, &hsp_unit, &walkq};
+            for (int i = 0; i < 10; i++) bufs[i]->set_view(carve(arena_q, &off, sz[i]), sz[i]);
+        }
         q.ctr = (ExtCounters *)ctr.p;
         q.cand = (Cand *)cand.p; q.fkey = (uint64_t *)fkey.p; q.fprev = (uint32_t *)fprev.p;
         q.medq = (uint2 *)medq.p; q.medu = (uint32_t *)medu.p; q.longq = (uint2 *)longq.p; q.longu = (uint32_t *)longu.p;
@@ -968,24 +993,29 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         }
         nf_total = nf; nm_total = nm;
         bool over = maxf > cap_f || maxm > cap_m || c.nlong > cap_l || c.ncand > cap_c || c.nwalk_over > 1024;
-        if (!over && nf && splittable_) {   // the sort's second buffers, flags, segment lists and rocPRIM's scratch: ~41 bytes per follower
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const uint64_t have = (uint64_t)free_b + fkey2.cap + fprev2.cap + flags.cap + segs.cap + bigseg.cap + tmp.cap;
-            if (nf * 41ull + (1ull << 30) > have) { release_queues(); return MIMEO_ERR_SPLIT; }
-        }
         if (!over && nf) {
-            if ((rc = fkey2.reserve(nf * 8)) || (rc = fprev2.reserve(nf * 4)) || (rc = flags.reserve(nf)) ||
-                (rc = segs.reserve(nf * 8)) || (rc = bigseg.reserve(nf * 8)))
-                return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
+            // the sort's second buffers, flags, segment lists and rocPRIM's scratch: slices of the second arena (~41 bytes per follower)
             size_t t1 = 0, t2 = 0;
+            rocprim::counting_iterator<uint64_t> iota(0);
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)nf, 0, key_bits, st));
+            HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nsel.p, (size_t)nf, st));
+            const size_t sz[6] = {nf * 8, nf * 4, nf, nf * 8, nf * 8, std::max(t1, t2) + 16};
+            size_t total = 0;
+            for (size_t z : sz) total += (z + 255) & ~(size_t)255;
+            if (total > arena_s.cap) {
+                for (DeviceBuf *d : {&fkey2, &fprev2, &flags, &segs, &bigseg, &tmp}) d->release();
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                size_t want = total + total / 2;
+                if (want + (4ull << 30) > free_b + arena_s.cap) want = total;
+                if ((rc = arena_s.reserve(want)) && want > total) rc = arena_s.reserve(total);
+                if (rc) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
+            }
+            size_t off = 0;
+            DeviceBuf *bufs[6] = {&fkey2, &fprev2, &flags, &segs, &bigseg, &tmp};
+            for (int i = 0; i < 6; i++) bufs[i]->set_view(carve(arena_s, &off, sz[i]), sz[i]);
             // the eight shards gathered into fkey2 / fprev2; the sort writes back into the (now free) shard area
             hipLaunchKernelGGL(k4_compact_followers, dim3(1024), dim3(256), 0, st, q, (uint64_t *)fkey2.p, (uint32_t *)fprev2.p);
-            HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
-                                              (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
-            rocprim::counting_iterator<uint64_t> iota(0);
-            HIP_TRY(rocprim::select(nullptr, t2, iota, (uint8_t *)flags.p, (uint64_t *)segs.p, (uint64_t *)nsel.p, (size_t)nf, st));
-            if ((rc = tmp.reserve(std::max(t1, t2) + 16))) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
             HIP_TRY(rocprim::radix_sort_pairs(tmp.p, t1, (uint64_t *)fkey2.p, (uint64_t *)fkey.p, (uint32_t *)fprev2.p,
                                               (uint32_t *)fprev.p, (size_t)nf, 0, key_bits, st));
             hipLaunchKernelGGL(k4_segment_flags, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, st, (const uint64_t *)fkey.p,
@@ -1052,6 +1082,9 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * expect_hits)));
             boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * expect_hits)));
             boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * expect_hits)));   // the counters count beyond the capacities
+            // ... and the fullest shard of the worst unit, not the batch's average, is what has to fit (microsatellites are not
+            // spread evenly over the pairs); shrink_ (tests) made the capacities smaller, not the need larger
+            boost_w = std::min(4096.0, std::max(boost_w, 1.5 * boost_w * ((double)c.nwalk_over / 1024.0) / shrink_));
         }
         {
             uint64_t budget = 0;
@@ -1059,7 +1092,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             if (getenv("MIMEO_TRACE"))
                 fprintf(stderr, "[trace] overflow of a batch of %u units: followers %llu (fullest shard), generic %llu, long %llu, cand %llu, walk %.2fx; queues would take %.2f GiB of %.2f GiB\n",
                         nunits, (unsigned long long)maxf, (unsigned long long)maxm, c.nlong, c.ncand, (double)c.nwalk_over / 1024.0, (double)queue_bytes() / (1 << 30), (double)budget / (1 << 30));
-            if (splittable_ && queue_bytes() > budget) { release_queues(); return MIMEO_ERR_SPLIT; }   // the caller cuts the batch in two
+            if (splittable_ && queue_bytes() > budget) return MIMEO_ERR_SPLIT;   // the caller cuts the batch in two
         }
         if ((rc = enqueue_heavy())) return rc;   // the batch again, on this stream, with room
     }
@@ -1084,6 +1117,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * e)));
         boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * e)));
         boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * e)));
+        boost_w = std::min(4096.0, std::max(boost_w, 1.5 * boost_w * ((double)c.nwalk_over / 1024.0) / shrink_));   // the fullest shard of the worst unit
     }
     if (stats) {
         for (uint32_t u = 0; u < nunits; u++) {

@@ -663,6 +663,10 @@ int align_units_impl(const mimeo_genome *A, const mimeo_genome *B, const uint32_
     g_stats.ms_chain = ms_chain;
     g_stats.ms_gapped = ms_gapped;
     g_stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("MIMEO_TRACE")) {
+        extern double g_alloc_ms;
+        fprintf(stderr, "[trace] call: %.1f ms in all, %.1f ms of it in hipMalloc / hipFree of work buffers (since the library was loaded: cumulative)\n", g_stats.ms_total, g_alloc_ms);
+    }
     return 0;
 }
 
