@@ -241,6 +241,7 @@ struct ExtBatch {
     void *q_ = nullptr;   // ExtQueues of the batch (k4_device.h), owned
     int enqueue_heavy();
     void release_queues();          // the big queue buffers back to the device pool
+    uint64_t arena_bytes() const;   // device bytes of the batch's queues at the current capacities
     uint64_t queue_bytes() const;   // device bytes the queues of the batch take at the current capacities
     uint64_t held_bytes() const;    // ... and what its buffers hold already
 };

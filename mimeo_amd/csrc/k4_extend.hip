@@ -684,9 +684,15 @@ int ExtBatch::run(const std::vector<UnitWork> &work, const mimeo_params *p, uint
 // predecessor / hit + unit), long walks, candidates + HSPs (+ their mirror copies), the walk queue of one unit.  The
 // follower sort's second buffer, flags, segment lists and rocPRIM's scratch are sized by the followers actually seen
 // (finish()): up to 41 bytes each on top.
+uint64_t ExtBatch::arena_bytes() const {   // the queues proper: what the first arena holds
+    const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
+    return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8) + 4096;
+}
+// ... plus what the rest of the batch may ask for while they are alive: the follower sort's second arena at its worst (every
+// shard full: 41 bytes per follower) and the chain / gapped stage's scratch and alignment slots (~200 bytes per HSP)
 uint64_t ExtBatch::queue_bytes() const {
     const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
-    return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8);
+    return arena_bytes() + cap_f_ * 8 * 41 + cap_c_ * mf * 200;
 }
 // carve `bytes` (rounded up to 256) off an arena at *off
 static void *carve(const DeviceBuf &arena, size_t *off, size_t bytes) {
@@ -701,12 +707,12 @@ void ExtBatch::release_queues() {
     arena_q.release();
     arena_s.release();
 }
-uint64_t ExtBatch::held_bytes() const { return arena_q.cap; }
+uint64_t ExtBatch::held_bytes() const { return arena_q.cap + arena_s.cap; }
 // free device memory plus what the batch's own buffers would give back, less a reserve for chain / gapped scratch
 static int queue_budget(const ExtBatch &b, uint64_t *budget) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t have = (uint64_t)free_b + b.held_bytes(), reserve = std::min<uint64_t>(have / 8, 4ull << 30);
+    const uint64_t have = (uint64_t)free_b + b.held_bytes(), reserve = std::min<uint64_t>(have / 8, 8ull << 30);
     *budget = have - reserve;
     if (getenv("MIMEO_QUEUE_BUDGET_MB")) *budget = (uint64_t)atol(getenv("MIMEO_QUEUE_BUDGET_MB")) << 20;   // tests: force the split
     return 0;
@@ -844,7 +850,7 @@ int ExtBatch::enqueue_heavy() {
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 const size_t have = free_b + arena_q.cap;
                 size_t want = total + total / 2;
-                if (want + (8ull << 30) > have) want = total;
+                if (want + (queue_bytes() - arena_bytes()) + (8ull << 30) > have) want = total;   // the sort arena and the chain scratch come after
                 if ((rc = arena_q.reserve(want)) && want > total) rc = arena_q.reserve(total);
                 if (rc) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
             }
