@@ -175,3 +175,35 @@ def test_one_pair_beyond_a_limit_is_left_out_and_the_others_are_returned(eng):
     eng.align_pairs(g, None, pairs)
     assert eng.failed_pairs() == []
     g.close()
+
+
+def test_cli_self_two_ranks_deal_units_and_write_the_files_of_one_process(tmp_path):
+    """`mimeo self` under torchrun (two gloo ranks sharing GPU 0) on five large-ish scaffolds: the ranks are dealt target rows
+    with the plus-strand pairs in both orders (dist.deal_units -> mimeo_align_units, shared plus strand inside each rank), and
+    rank 0 writes the TAB / GFF3 of a single process — also with --strictSelf (the intra-scaffold rows in their own file)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from mimeo_amd.synth import write_fasta
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names, seqs = synth_genome(47, 5 * 300_000, 5, repeat_frac=0.15, families=5, cons_len=(200, 2000), max_div=0.12)
+    fa = str(tmp_path / 'five.fa')
+    write_fasta(fa, names, seqs)
+    for extra, files in (([], ('mimeo_alignment.tab', 'mimeo-self_repeats.gff3')),
+                         (['--strictSelf'], ('mimeo_alignment.tab', 'mimeo_alignment.tab_intra.tab', 'mimeo-self_repeats.gff3'))):
+        args = ['self', '--afasta', fa, '--minIdt', '80', '--minLen', '100', '--minCov', '3'] + extra
+        tag = 's' if extra else 'p'
+        one = subprocess.run([sys.executable, '-m', 'mimeo_amd'] + args + ['-d', str(tmp_path / ('one' + tag))], cwd=root, capture_output=True, text=True,
+                             timeout=600)
+        assert one.returncode == 0, one.stdout + one.stderr
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        env2 = dict(os.environ, MIMEO_DIST_BACKEND='gloo', MIMEO_FORCE_DEVICE='0')
+        two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                              '--master-port', str(port), '-m', 'mimeo_amd'] + args + ['-d', str(tmp_path / ('two' + tag))], cwd=root,
+                             capture_output=True, text=True, timeout=900, env=env2)
+        assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+        for f in files:
+            a, b = (tmp_path / ('one' + tag) / f).read_text(), (tmp_path / ('two' + tag) / f).read_text()
+            assert a == b, (extra, f)
+        assert (tmp_path / ('one' + tag) / 'mimeo_alignment.tab').read_text().count('\n') > 30
