@@ -799,7 +799,7 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
         const UnitWork &w = work[u];
         if (!w.ti.n || !w.qi.n) continue;
         const double e = 13.0 * (double)w.ti.n * (double)w.qi.n / 16777216.0;
-        walk_cap_u_[u] = (uint64_t)(e * 0.12 / 8 * 1.5 * boost_w / shrink) + (uint64_t)(16384 / shrink) + 64;
+        walk_cap_u_[u] = (uint64_t)(e * 0.08 / 8 * 1.5 * boost_w / shrink) + (uint64_t)(16384 / shrink) + 64;
         walk_entries_ += 8 * walk_cap_u_[u];
     }
     {   // a batch whose queues cannot fit is cut in two by the caller before anything is allocated (a single unit is tried anyway)
@@ -849,7 +849,9 @@ int ExtBatch::enqueue_heavy() {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 const size_t have = free_b + arena_q.cap;
-                size_t want = total + total / 2;
+                // the first allocation is what the batch asks for; one that has to grow (an overflow, a larger batch) takes half as much
+                // again when the device has it, so that the next one does not allocate (hipMalloc costs ~35 ms per GiB)
+                size_t want = arena_q.cap ? total + total / 2 : total;
                 if (want + (queue_bytes() - arena_bytes()) + (8ull << 30) > have) want = total;   // the sort arena and the chain scratch come after
                 if ((rc = arena_q.reserve(want)) && want > total) rc = arena_q.reserve(total);
                 if (rc) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
@@ -1012,7 +1014,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
                 for (DeviceBuf *d : {&fkey2, &fprev2, &flags, &segs, &bigseg, &tmp}) d->release();
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-                size_t want = total + total / 2;
+                size_t want = arena_s.cap ? total + total / 2 : total + total / 8;
                 if (want + (4ull << 30) > free_b + arena_s.cap) want = total;
                 if ((rc = arena_s.reserve(want)) && want > total) rc = arena_s.reserve(total);
                 if (rc) return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
@@ -1087,7 +1089,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
             boost_m = std::min(4096.0, std::max(boost_m, 1.5 * (double)(8 * maxm) / (0.03 * expect_hits)));
             boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * expect_hits)));
             boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * expect_hits)));
-            boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * expect_hits)));   // the counters count beyond the capacities
+            boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.08 * expect_hits)));   // the counters count beyond the capacities
             // ... and the fullest shard of the worst unit, not the batch's average, is what has to fit (microsatellites are not
             // spread evenly over the pairs); shrink_ (tests) made the capacities smaller, not the need larger
             boost_w = std::min(4096.0, std::max(boost_w, 1.5 * boost_w * ((double)c.nwalk_over / 1024.0) / shrink_));
@@ -1122,18 +1124,19 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         boost_m = std::min(4096.0, std::max(boost_m, 1.5 * (double)nm_total / (0.03 * e)));
         boost_l = std::min(4096.0, std::max(boost_l, 1.5 * (double)c.nlong / (0.002 * e)));
         boost_c = std::min(4096.0, std::max(boost_c, 1.5 * (double)c.ncand / (0.002 * e)));
-        boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.12 * e)));
+        boost_w = std::min(4096.0, std::max(boost_w, 1.5 * (double)c.nwalk_total / (0.08 * e)));
         boost_w = std::min(4096.0, std::max(boost_w, 1.5 * boost_w * ((double)c.nwalk_over / 1024.0) / shrink_));   // the fullest shard of the worst unit
     }
     if (stats) {
         for (uint32_t u = 0; u < nunits; u++) {
+            if (!(work[u].ti.n && work[u].qi.n)) continue;   // a mirror unit's seed scan is never run: it counts no hits and no bytes
             stats->seed_hits += h_unit_hits[u];
             const uint64_t Lq = work[u].d.Q.len, H = h_unit_hits[u];
             // B_scan = ceil(Lq/4) + 8*W*(Lq-18) + 4*H + 8*H, W = 13
             stats->scan_bytes_algorithmic += (Lq + 3) / 4 + (Lq > 18 ? 8ull * 13ull * (Lq - 18) : 0) + 12ull * H;
             // compulsory traffic of the fused kernel: both offset arrays, positions and frames of both sides once
             stats->scan_bytes_kernel += 2ull * 4ull * ((uint64_t)NBUCKET + 1) + 52ull * ((uint64_t)work[u].ti.n + work[u].qi.n);
-            if (work[u].ti.n && work[u].qi.n) stats->heavy_launches++;   // units: the seed-scan kernel takes a batch of them per launch
+            stats->heavy_launches++;   // units: the seed-scan kernel takes a batch of them per launch
         }
         if (!v1 && nactive_) stats->heavy_kernel_launches++;
         stats->walked += c.nwalked;

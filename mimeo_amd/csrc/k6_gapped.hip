@@ -1098,6 +1098,9 @@ __global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict
         best.maxcols = max(best.maxcols, hi - lo + 1u);
         best.rows = i;
         if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.nm; best.nx = tb.nx; }
+        // the cells are 32 bits wide (as lastz's own score_t): a half extension that nears 2^31 — 20 Mbp of near-identity without a
+        // break — is refused before it wraps; its pair is left out and named (mimeo_get_failed_pairs)
+        if (best.score > 2000000000) { overflow = true; break; }
     }
     best.overflow = overflow ? 1u : 0u;
     if (tid == 0) res[job.slot] = best;

@@ -218,17 +218,18 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     if (rc) { side_t.release(); side_q.release(); return rc; }
     SuperSide &ST = side_t, &SQ = self ? side_t : side_q;
     struct Cleanup { SuperSide &a, &b; ~Cleanup() { a.release(); b.release(); } } cleanup{side_t, side_q};
-    // seed indexes of the supers must fit (no index blocks on this path: the unit-per-pair path has them)
+    // seed indexes of the supers: when they do not all fit (60 % of the free device memory; a 3 Gbp fragmented assembly needs
+    // 330 GB of them) the super x super matrix is cut into index blocks, as on the unit-per-pair path
+    uint64_t idx_need = 0, idx_budget = 0, idx_tmax = 1, idx_qmax = 1;
     {
-        uint64_t need = 0;
         const int qroles = ((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH) ? 2 : 1;
-        for (auto &s : ST.supers) need += seed_index_bytes(s.len);
-        for (auto &s : SQ.supers) need += seed_index_bytes(s.len) * qroles;
+        for (auto &s : ST.supers) { idx_need += seed_index_bytes(s.len); idx_tmax = std::max(idx_tmax, seed_index_bytes(s.len)); }
+        for (auto &s : SQ.supers) { idx_need += seed_index_bytes(s.len) * qroles; idx_qmax = std::max(idx_qmax, seed_index_bytes(s.len) * qroles); }
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        uint64_t budget = (uint64_t)(0.6 * (double)free_b);
-        if (sw.index_budget_mb) budget = sw.index_budget_mb << 20;
-        if (need > budget) return 0;
+        idx_budget = (uint64_t)(0.6 * (double)free_b);
+        if (sw.index_budget_mb) idx_budget = sw.index_budget_mb << 20;
+        if (idx_tmax + idx_qmax > idx_budget) return 0;   // not even one pair of supers: the other path cuts finer
     }
     *used = true;
     hipStream_t st = stream();
@@ -286,27 +287,45 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
             }
     for (auto &s : ST.supers) max_t = std::max<uint64_t>(max_t, s.len);
     for (auto &s : SQ.supers) max_q = std::max<uint64_t>(max_q, s.len);
+    std::vector<size_t> block_end;   // unit index where each index block ends
+    if (idx_need > idx_budget && !units.empty()) {
+        const uint64_t Bt = std::max<uint64_t>(1, idx_budget / 2 / idx_tmax), Bq = std::max<uint64_t>(1, idx_budget / 2 / idx_qmax);
+        std::stable_sort(units.begin(), units.end(), [&](const SUnit &a, const SUnit &b) {
+            const uint64_t ta = a.ts / Bt, tb = b.ts / Bt, qa = a.qs / Bq, qb = b.qs / Bq;
+            if (ta != tb) return ta < tb;
+            if (qa != qb) return qa < qb;
+            return a.ts < b.ts;   // target-major inside a block
+        });
+        for (size_t i = 1; i <= units.size(); i++)
+            if (i == units.size() || units[i].ts / Bt != units[i - 1].ts / Bt || units[i].qs / Bq != units[i - 1].qs / Bq) block_end.push_back(i);
+    } else {
+        block_end.push_back(units.size());
+    }
+    size_t max_units = std::min<size_t>(8192, ext_batch_max_units(max_t, max_q));
+    if (sw.batch_units) max_units = std::min<size_t>(max_units, sw.batch_units);
+    double max_hits = sw.batch_hits;
+    const uint64_t max_groups = 1ull << 22;   // K5 names a group in 23 bits
+    size_t blk_begin = 0;
+    for (size_t blk = 0; blk < block_end.size() && !rc; blk_begin = block_end[blk], blk++) {
+    const size_t blk_end = block_end[blk];
     IndexCache cache;
     {
         std::set<IndexCache::Key> seen;
-        for (const SUnit &u : units) {
+        for (size_t i = blk_begin; i < blk_end; i++) {
+            const SUnit &u = units[i];
             cache.want(nullptr, ST.supers[u.ts], 0, true, seen);
             cache.want(nullptr, SQ.supers[u.qs], (int)u.minus, false, seen);
         }
     }
     rc = cache.build_all();
-    size_t max_units = std::min<size_t>(8192, ext_batch_max_units(max_t, max_q));
-    if (sw.batch_units) max_units = std::min<size_t>(max_units, sw.batch_units);
-    double max_hits = sw.batch_hits;
-    const uint64_t max_groups = 1ull << 22;   // K5 names a group in 23 bits
-    for (size_t b0 = 0; b0 < units.size() && !rc;) {
+    for (size_t b0 = blk_begin; b0 < blk_end && !rc;) {
         std::vector<UnitWork> work;
         std::vector<uint3> utab;
         std::vector<uint32_t> mirror_dst;
         double hits = 0;
         uint64_t tmembers = 0;
         size_t b1 = b0;
-        for (; b1 < units.size(); b1++) {
+        for (; b1 < blk_end; b1++) {
             const SUnit &u = units[b1];
             if (work.size() + (u.mirrored ? 2 : 1) > max_units && !work.empty()) break;
             UnitWork w;
@@ -381,6 +400,7 @@ static int run_packed(const mimeo_genome *A, const mimeo_genome *QG, const uint3
     cache.clear();
     ms_index += cache.ms;
     g_stats.index_blocks++;
+    }   // index blocks
     g_stats.pair_strands += distinct * (((p->strand & MIMEO_STRAND_BOTH) == MIMEO_STRAND_BOTH) ? 2 : 1);
     if (!rc)
         for (auto &d : dups) { per_pair[d.first] = per_pair[d.second]; if (failed[d.second]) failed[d.first] = 1; }

@@ -11,7 +11,7 @@ from mimeo_amd.synth import synth_genome, make_families
 
 pytestmark = pytest.mark.gpu
 
-PACK_KNOBS = ('MIMEO_PACK', 'MIMEO_PACK_MIN', 'MIMEO_PACK_SUPER', 'MIMEO_PACK_MEMBER', 'MIMEO_BATCH_UNITS')
+PACK_KNOBS = ('MIMEO_PACK', 'MIMEO_PACK_MIN', 'MIMEO_PACK_SUPER', 'MIMEO_PACK_MEMBER', 'MIMEO_BATCH_UNITS', 'MIMEO_INDEX_BUDGET_MB')
 
 
 @pytest.fixture(scope='module')
@@ -55,7 +55,9 @@ def test_packed_self_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
     assert st0['super_units'] == 0 and st0['pair_strands'] == 2 * 24 * 24
     outs = {}
     for tag, env in (('one_super', {}), ('three_supers', {'MIMEO_PACK_SUPER': '250000'}), ('supers_of_two', {'MIMEO_PACK_SUPER': '50000'}),
-                     ('big_ones_alone', {'MIMEO_PACK_MEMBER': '24000', 'MIMEO_PACK_MIN': '2'}), ('one_unit_batches', {'MIMEO_BATCH_UNITS': '1', 'MIMEO_PACK_SUPER': '250000'})):
+                     ('big_ones_alone', {'MIMEO_PACK_MEMBER': '24000', 'MIMEO_PACK_MIN': '2'}), ('one_unit_batches', {'MIMEO_BATCH_UNITS': '1', 'MIMEO_PACK_SUPER': '250000'}),
+                     # the supers' seed indexes (77 MB each, three roles) do not fit 400 MB: index blocks over the super x super matrix
+                     ('index_blocks', {'MIMEO_PACK_SUPER': '250000', 'MIMEO_INDEX_BUDGET_MB': '400'})):
         _clear(monkeypatch)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -66,6 +68,7 @@ def test_packed_self_alignments_equal_the_unit_per_pair_path(eng, monkeypatch):
         outs[tag] = _digest(a)
         if tag == 'one_super':
             assert st['super_units'] == 2
+        assert (st['index_blocks'] > 1) == (tag == 'index_blocks'), (tag, st['index_blocks'])
     _clear(monkeypatch)
     assert ref.size > 50
     assert set(outs.values()) == {_digest(ref)}, (outs, _digest(ref))
