@@ -228,6 +228,7 @@ struct ExtBatch {
     // hipMalloc / hipFree of tens of GB cost seconds (C5 at full size spent 80 % of its wall time there): the queues of a batch are
     // slices of ONE allocation that only ever grows (arena_q, carved per batch), the follower sort's buffers of another (arena_s)
     DeviceBuf arena_q, arena_s;
+    DeviceBuf plan_buf;          // the split pass's plan (k34_plan)
     DeviceBuf funits, nwalk_u;   // per-unit table of the heavy kernels (FusedUnit); walk-queue counters per unit and shard + split-pass tile counts
     std::vector<uint64_t> walk_cap_u_;   // walk-queue capacity per unit and shard
     uint64_t walk_entries_ = 0;          // ... all regions together

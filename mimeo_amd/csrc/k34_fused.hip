@@ -35,8 +35,12 @@ constexpr uint32_t TCH = 64;      // target entries per wavefront and chunk: one
 constexpr uint32_t DQ = 192;      // pair descriptors per wavefront and round
 constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CARE19
 constexpr unsigned long long HEAVY_HITS = 262144;   // hits of a tile beyond which it is split (a tile of a 10 Mbp x 10 Mbp unit averages 19 000)
-constexpr uint32_t HEAVY_MAX = 64;     // x extent of the split pass grid: its workgroups loop over the listed tiles
-constexpr uint32_t HEAVY_SPLIT = 8, HEAVY_QSPLIT = 8;   // ... over 8 shares of its target chunks x 8 shares of its query segments
+// The split pass works the listed tiles off in PARTS of about PART_HITS seed hits each (k34_plan: a tile's parts = shares of its
+// target chunk groups x ranges of its query entries), dealt to persistent workgroups by an atomic counter: a poly-A tile of
+// 6000 x 6000 entries (3.6e7 hits) is 280 parts, a tile just above the threshold two — the static 8 x 8 split of round 2 left the
+// machine to the 64 workgroups of the largest tile (C5: 55 ps per seed hit in this pass against 13.5 in the first).
+constexpr unsigned long long PART_HITS = 131072;
+constexpr uint32_t HEAVY_GRID = 2048;  // persistent workgroups of the split pass (four per workgroup slot of the device)
 
 // One launch works off EVERY unit of a batch (grid.y = the batch's units that have seed hits to look for): the machine never
 // drains between units (a launch per unit left ~6 % of it idle in the tails of 4096 workgroups over 512 slots, and cost three
@@ -45,6 +49,7 @@ constexpr uint32_t HEAVY_SPLIT = 8, HEAVY_QSPLIT = 8;   // ... over 8 shares of 
 struct FusedArgs {
     const FusedUnit *units;
     ExtQueues q;
+    HeavyPlan plan;
     int xdrop, hspthresh, transitions;
     uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on
 };
@@ -186,8 +191,10 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // first pass: grid (tiles, units); split pass: grid (HEAVY_MAX x units, target shares, query shares)
-    const uint32_t ai = HEAVY ? blockIdx.x / HEAVY_MAX : blockIdx.y;
-    const FusedUnit U = A.units[ai];   // by value: wave-uniform registers for the whole kernel, not a reload through the pointer at every use
+    uint32_t ai = HEAVY ? 0u : blockIdx.y;
+    FusedUnit U = A.units[ai];   // by value: wave-uniform registers, not a reload through the pointer at every use (split pass: set per part)
+    // split pass: my part of the tile = target chunk groups p, p + Pt, ... and the query entries [qa, qb)
+    uint32_t part_p = 0, part_pt = 1, part_qa = 0, part_qb = 0xFFFFFFFFu, part_no = 0;
     uint32_t *sD = sD_all + wv * DQ;
     uint2 *s_walk = s_walk_all + wv * 64;
     uint32_t n_walk = 0;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long b = 0;
         // (split pass: the 64 workgroups that share a tile have one blockIdx.x — spread them, or a microsatellite tile fills one shard)
-        const uint32_t shard = (HEAVY ? blockIdx.x + blockIdx.y + blockIdx.z : blockIdx.x) & 7u;
+        const uint32_t shard = (HEAVY ? blockIdx.x + part_no : blockIdx.x) & 7u;
         if (lane == 0) b = atomicAdd(&A.q.nwalk_u[(size_t)ai * 8 + shard], (unsigned long long)n);
         b = __shfl(b, 0);
         if (lane < n && b + lane < U.walk_cap) A.q.walkq[U.walk_base + (size_t)shard * U.walk_cap + b + lane] = s_walk[lane];
@@ -210,7 +217,6 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         const uint32_t t0 = toff[0], nT = toff[TILE_WORDS] - t0;
         const uint32_t q0 = qoff[0], nQ = qoff[TILE_WORDS] - q0;
         if (!nT || !nQ) return;   // tile_hits is zeroed per batch
-        if (HEAVY && blockIdx.z * QSEG >= nQ) return;   // no query segment for this share
         if (!HEAVY) {
             // A tile with far more hits than the average — a microsatellite's seed words: thousands of entries of ONE key on both
             // sides, 10^7-10^8 hits in one tile — or with more query entries than 16-bit offsets can name is not worked off by
@@ -246,7 +252,11 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             }
             const unsigned long long tile_est = *s_total * (A.transitions ? (unsigned long long)(SEED_WEIGHT + 1) : 1ull);
             if (tile_est > HEAVY_HITS || nQ > 0xFFFFu) {   // (a tile of 65536 query entries and more: 52 segments for one workgroup)
-                if (threadIdx.x == 0) A.q.heavy[(size_t)ai * NTILE + atomicAdd(&A.q.nheavy_u[ai], 1ull)] = tile;   // at most NTILE entries per unit
+                if (threadIdx.x == 0) {   // at most NTILE entries per unit
+                    const size_t slot = (size_t)ai * NTILE + atomicAdd(&A.q.nheavy_u[ai], 1ull);
+                    A.q.heavy[slot] = tile;
+                    A.q.heavy_est[slot] = tile_est;
+                }
                 return;
             }
         }
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         const uint4 *tF0 = U.T.fr + t0, *tF1 = tF0 + U.T.fr_stride, *tF2 = tF1 + U.T.fr_stride;
         const uint32_t nchunks = (nT + TCH - 1) / TCH;
         // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
-        const uint32_t ch_first = (HEAVY ? blockIdx.y * WAVES : 0u) + wv, ch_step = (HEAVY ? gridDim.y : 1u) * WAVES;
+        const uint32_t ch_first = (HEAVY ? part_p * WAVES : 0u) + wv, ch_step = (HEAVY ? part_pt : 1u) * WAVES;
         // my first chunk's frames (one entry per lane): in flight while the first query segment is staged
         uint4 nf0 = make_uint4(0, 0, 0, 0), nf1 = nf0, nf2 = nf0;
         uint32_t npos = 0;
@@ -273,9 +283,9 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
         }
         unsigned long long hits_acc = 0;   // pairs this wavefront enumerates in this tile (wave-uniform): the tile's exact hit count
-        const uint32_t qs_first = HEAVY ? blockIdx.z * QSEG : 0u, qs_step = (HEAVY ? gridDim.z : 1u) * QSEG;
-        for (uint32_t qs = qs_first; qs < nQ; qs += qs_step) {
-            const uint32_t qn = min(QSEG, nQ - qs), qe = qs + qn;
+        const uint32_t q_begin = HEAVY ? part_qa : 0u, q_end = HEAVY ? min(part_qb, nQ) : nQ;
+        for (uint32_t qs = q_begin; qs < q_end; qs += QSEG) {
+            const uint32_t qn = min(QSEG, q_end - qs), qe = qs + qn;
             __syncthreads();  // every wavefront is through with the previous segment (and with the count prologue's use of the frame area)
             // the tile's offsets relative to this segment, clamped to it: key w's entries inside the segment are sQ[w] .. sQ[w + 1]
 #pragma unroll
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 const uint32_t mypos = npos;
                 {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
                     uint32_t nx = ch + ch_step;
-                    if (nx >= nchunks) nx = (qs + qs_step < nQ) ? ch_first : 0xFFFFFFFFu;
+                    if (nx >= nchunks) nx = (qs + QSEG < q_end) ? ch_first : 0xFFFFFFFFu;
                     if (nx != 0xFFFFFFFFu && nx != ch) {
                         const uint32_t e = nx * TCH + lane;
                         if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
@@ -413,10 +423,32 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
     if (!HEAVY) {
         do_tile(blockIdx.x);
     } else {
-        const uint32_t nlist = (uint32_t)min((unsigned long long)NTILE, A.q.nheavy_u[ai]);
-        for (uint32_t li = blockIdx.x % HEAVY_MAX; li < nlist; li += HEAVY_MAX) {
-            do_tile(A.q.heavy[(size_t)ai * NTILE + li]);
-            __syncthreads();   // the next tile's offsets overwrite this one's
+        // persistent workgroups: parts are handed out by a counter until none is left (every workgroup reaches the end: the loop
+        // bound is the plan's part count, fixed before this launch)
+        __shared__ uint32_t s_part;
+        const uint32_t nparts = A.plan.ctr[2], ntiles = A.plan.ctr[1];
+        for (;;) {
+            __syncthreads();   // the part before is finished in every wavefront (s_part, the tile's offsets and frames are free)
+            if (threadIdx.x == 0) s_part = atomicAdd(&A.plan.ctr[0], 1u);
+            __syncthreads();
+            const uint32_t g = s_part;
+            if (g >= nparts) break;
+            // the listed tile that holds part g: base[k] <= g < base[k + 1]
+            uint32_t lo = 0, hi = ntiles;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (A.plan.base[mid] <= g) lo = mid; else hi = mid;
+            }
+            const uint2 ut = A.plan.tile[lo];
+            const uint4 sp = A.plan.split[lo];
+            const uint32_t part = g - A.plan.base[lo];
+            if (n_walk && ut.x != ai) { flush_walk(n_walk); n_walk = 0; }   // the staged hits belong to the unit before
+            ai = ut.x;
+            U = A.units[ai];
+            part_no = part;
+            part_p = part % sp.x; part_pt = sp.x;
+            part_qa = (part / sp.x) * sp.z; part_qb = part_qa + sp.z;
+            do_tile(ut.y);
         }
     }
     if (n_walk) flush_walk(n_walk);
@@ -440,13 +472,63 @@ void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st) {
     hipLaunchKernelGGL(k34_sum_hits, dim3(nunits), dim3(256), 0, st, (const unsigned long long *)q.tile_hits, q.unit_hits);
 }
 
-// The split pass is launched with a fixed grid per unit: its workgroups loop over the tiles the first pass listed for their unit,
-// each cut over HEAVY_SPLIT shares of its target chunks x HEAVY_QSPLIT shares of its query segments (4096 workgroups per unit
-// that exit at once when no tile is listed: a few microseconds)
+// The plan of the split pass, one workgroup for the whole launch (a few thousand listed tiles; the worst case, every tile of every
+// unit listed, is a few milliseconds): the units' lists made dense, every tile cut into parts of about PART_HITS hits — target chunk
+// groups (512 entries: one chunk per wavefront of a workgroup) dealt round-robin over Pt shares, query entries in ranges of a
+// multiple of 64 — and the parts' prefix sum.
+__global__ __launch_bounds__(1024) void k34_plan(const FusedUnit *__restrict__ units, uint32_t nunits, ExtQueues q, HeavyPlan P) {
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_carry, s_tiles;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { s_carry = 0; s_tiles = 0; }
+    __syncthreads();
+    for (uint32_t u = 0; u < nunits; u++) {
+        const uint32_t nlist = (uint32_t)min((unsigned long long)NTILE, q.nheavy_u[u]);
+        const FusedUnit U = units[u];
+        for (uint32_t i0 = 0; i0 < nlist; i0 += 1024) {
+            const uint32_t i = i0 + tid;
+            uint32_t parts = 0, pt = 1, pq = 1, qlen = 0, tile = 0;
+            if (i < nlist) {
+                tile = q.heavy[(size_t)u * NTILE + i];
+                const unsigned long long est = P.est[(size_t)u * NTILE + i];
+                const uint32_t *toff = U.T.off + (size_t)tile * TILE_WORDS, *qoff = U.Q.off + (size_t)tile * TILE_WORDS;
+                const uint32_t nT = toff[TILE_WORDS] - toff[0], nQ = qoff[TILE_WORDS] - qoff[0];
+                const uint32_t want = (uint32_t)min((unsigned long long)(1u << 20), (est + PART_HITS - 1) / PART_HITS);
+                const uint32_t groups = max(1u, (nT + 511u) / 512u);
+                pt = min(groups, max(1u, want));
+                const uint32_t need_q = max(1u, (want + pt - 1) / pt);
+                qlen = max(64u, (((nQ + need_q - 1) / need_q) + 63u) & ~63u);
+                pq = max(1u, (nQ + qlen - 1) / qlen);
+                parts = pt * pq;
+            }
+            // exclusive scan of the parts over the 1024 lanes, carried from iteration to iteration
+            s_scan[tid] = parts;
+            __syncthreads();
+            for (uint32_t o = 1; o < 1024; o <<= 1) {
+                const uint32_t v = tid >= o ? s_scan[tid - o] : 0u;
+                __syncthreads();
+                s_scan[tid] += v;
+                __syncthreads();
+            }
+            if (i < nlist) {
+                const uint32_t k = s_tiles + (i - i0);
+                P.tile[k] = make_uint2(u, tile);
+                P.split[k] = make_uint4(pt, pq, qlen, 0u);
+                P.base[k] = s_carry + s_scan[tid] - parts;
+            }
+            __syncthreads();
+            if (tid == 1023) { s_carry += s_scan[1023]; s_tiles += min(1024u, nlist - i0); }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { P.base[s_tiles] = s_carry; P.ctr[0] = 0; P.ctr[1] = s_tiles; P.ctr[2] = s_carry; }
+}
+
 constexpr uint32_t QSEG_FIRST = 1280, QSEG_HEAVY = 1024;
 
 // the heavy phase of a batch: `nactive` units (table d_units), both passes
-int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const mimeo_params *p, hipStream_t st, uint32_t dbg) {
+int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const HeavyPlan &plan, const mimeo_params *p, hipStream_t st,
+                       uint32_t dbg) {
     if (!nactive) return 0;
     FusedArgs A;
     A.units = d_units; A.q = q;
@@ -464,13 +546,17 @@ int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueu
     });
     HIP_TRY(attr_err);
     // measured on a C4 unit (two segments per tile at 1280, three at 1216 and 1024): 1.44 / 1.51 / 1.54 ms for the heavy phase
-    for (uint32_t u0 = 0; u0 < nactive; u0 += 32768u) {   // grid.y and grid.x limits
+    for (uint32_t u0 = 0; u0 < nactive; u0 += 32768u) {   // grid.y limit
         const uint32_t nu = std::min(32768u, nactive - u0);
-        A.units = d_units + u0;
         FusedArgs B = A;
+        B.units = d_units + u0;
         B.q.nwalk_u = q.nwalk_u + (size_t)u0 * 8; B.q.nheavy_u = q.nheavy_u + u0; B.q.heavy = q.heavy + (size_t)u0 * NTILE;
+        B.q.heavy_est = q.heavy_est + (size_t)u0 * NTILE;
+        B.plan = plan;
+        B.plan.est = B.q.heavy_est;
         hipLaunchKernelGGL((k34_scan_extend<512, QSEG_FIRST, false>), dim3(NTILE, nu), dim3(512), smem_first, st, B);
-        hipLaunchKernelGGL((k34_scan_extend<512, QSEG_HEAVY, true>), dim3(HEAVY_MAX * nu, HEAVY_SPLIT, HEAVY_QSPLIT), dim3(512), smem_heavy, st, B);
+        hipLaunchKernelGGL(k34_plan, dim3(1), dim3(1024), 0, st, B.units, nu, B.q, B.plan);
+        hipLaunchKernelGGL((k34_scan_extend<512, QSEG_HEAVY, true>), dim3(HEAVY_GRID), dim3(512), smem_heavy, st, B);
     }
     return 0;
 }

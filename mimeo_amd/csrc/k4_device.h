@@ -25,6 +25,13 @@ struct ExtCounters {
     unsigned long long dbg[8];  // development (MIMEO_K34_DEBUG & 8): why the pre-filter passed a hit on
 };
 
+struct HeavyPlan {                       // the listed tiles of the whole batch, dense (k34_plan)
+    const unsigned long long *est;       // per listed slot (unit * NTILE + i): the first pass's estimate of the tile's hits
+    uint2 *tile;                         // dense k -> (unit index in the launch, tile)
+    uint32_t *base;                      // dense k -> first part; base[ntiles] = all parts
+    uint4 *split;                        // dense k -> (target shares, query ranges, entries per query range, 0)
+    unsigned int *ctr;                   // [0] parts handed out, [1] listed tiles, [2] parts
+};
 struct Cand {
     uint32_t tstart, qstart, len;
     int32_t raw;  // RAW_SATURATED: the score does not fit (a gap-free segment beyond ~21 Mbp); k4_entropy recounts it in 64 bits
@@ -47,6 +54,7 @@ struct ExtQueues {
     unsigned long long *nwalk_u;    // ... entries per unit and shard (workgroup number mod 8, i.e. per XCD)
     unsigned long long *nheavy_u;   // tiles per unit that K34's first pass left to its split pass
     uint32_t *heavy;                // ... their numbers: NTILE slots per unit
+    unsigned long long *heavy_est;  // ... and the first pass's estimates of their hits (the split pass is planned from them)
     unsigned long long *bigcand;    // indices of the long candidates (ENT_BIGCAP) and their accumulators: 5 per candidate
     unsigned long long *bigacc;     // ... matched A / C / G / T columns, raw score
     unsigned long long *unit_hits;  // seed hits per unit (statistics)

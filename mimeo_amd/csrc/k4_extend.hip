@@ -641,12 +641,13 @@ const uint32_t *group_table_device() {
 }
 
 // fused heavy kernel (k34_fused.hip)
-int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const mimeo_params *p, hipStream_t st, uint32_t dbg);
+int launch_fused_batch(const FusedUnit *d_units, uint32_t nactive, const ExtQueues &q, const HeavyPlan &plan, const mimeo_params *p, hipStream_t st,
+                       uint32_t dbg);
 void launch_sum_hits(const ExtQueues &q, uint32_t nunits, hipStream_t st);
 
 void ExtBatch::release() {
     for (DeviceBuf *b : {&units, &ctr, &cand, &fkey, &fkey2, &fprev, &fprev2, &medq, &medu, &longq, &longu, &walkq, &flags, &segs, &tmp,
-                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror, &funits, &nwalk_u, &arena_q, &arena_s})
+                         &nsel, &bigseg, &hsps, &hsp_unit, &unit_hits, &tile_hits, &selfs, &hits, &bigcand, &bigacc, &heavy, &mirror, &funits, &nwalk_u, &plan_buf, &arena_q, &arena_s})
         b->release();
     jc.release();
     for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
@@ -772,7 +773,7 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
     int rc;
     if ((rc = units.reserve((size_t)nunits * sizeof(UnitDesc))) || (rc = ctr.reserve(sizeof(ExtCounters))) ||
         (rc = unit_hits.reserve((size_t)nunits * 8)) || (rc = nsel.reserve(16)) ||
-        (rc = tile_hits.reserve(v1_ ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) || (rc = heavy.reserve(4096 * 4)) ||
+        (rc = tile_hits.reserve(v1_ ? 8 : (size_t)nunits * NTILE * 8)) || (rc = bigcand.reserve((size_t)ENT_BIGCAP * 8)) ||
         (rc = bigacc.reserve((size_t)ENT_BIGCAP * 5 * 8)) ||
         (rc = selfs.reserve((h_selfs_.size() + 1) * 4)))
         return rc;
@@ -906,10 +907,19 @@ int ExtBatch::enqueue_heavy() {
             if (nactive) {
                 h_funits_ = std::move(h_fu);   // a member: the copy below is asynchronous
                 // counters: 8 walk-queue shards per unit, then the split-pass tile counts
+                // the split pass's tile lists (number + estimate per slot) and its plan (dense tiles, part bases, splits, counters)
+                const size_t slots = (size_t)std::min(nactive, 32768u) * NTILE;
                 if ((rc = funits.reserve((size_t)nactive * sizeof(FusedUnit))) || (rc = nwalk_u.reserve((size_t)nactive * 9 * 8)) ||
-                    (rc = heavy.reserve((size_t)nactive * NTILE * 4)))
+                    (rc = heavy.reserve((size_t)nactive * NTILE * 12)) || (rc = plan_buf.reserve(slots * 28 + 4096)))
                     return rc == MIMEO_ERR_NOMEM && splittable_ ? MIMEO_ERR_SPLIT : rc;
-                q.heavy = (uint32_t *)heavy.p;
+                q.heavy_est = (unsigned long long *)heavy.p;
+                q.heavy = (uint32_t *)(q.heavy_est + (size_t)nactive * NTILE);
+                HeavyPlan plan;
+                plan.est = q.heavy_est;
+                plan.split = (uint4 *)plan_buf.p;                       // slots * 16
+                plan.tile = (uint2 *)(plan.split + slots);              // slots * 8
+                plan.base = (uint32_t *)(plan.tile + slots);            // (slots + 1) * 4
+                plan.ctr = (unsigned int *)(plan.base + slots + 4);     // 3 counters
                 q.nwalk_u = (unsigned long long *)nwalk_u.p;
                 q.nheavy_u = q.nwalk_u + (size_t)nactive * 8;
                 HIP_TRY(hipMemcpyAsync(funits.p, h_funits_.data(), (size_t)nactive * sizeof(FusedUnit), hipMemcpyHostToDevice, st));
@@ -920,7 +930,7 @@ int ExtBatch::enqueue_heavy() {
                     kev.push_back(e);
                 }
                 HIP_TRY(hipEventRecord(kev[0], st));
-                if ((rc = launch_fused_batch((const FusedUnit *)funits.p, nactive, q, p, st, k34_dbg_))) return rc;
+                if ((rc = launch_fused_batch((const FusedUnit *)funits.p, nactive, q, plan, p, st, k34_dbg_))) return rc;
                 HIP_TRY(hipEventRecord(kev[1], st));
                 for (uint32_t u0 = 0; u0 < nactive; u0 += 32768u) {
                     const uint32_t nu = std::min(32768u, nactive - u0);
