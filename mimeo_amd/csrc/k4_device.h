@@ -21,6 +21,7 @@ struct ExtCounters {
     // makes ~10^4 flushes.  nfollow / nmed hold the totals once k4_compact has gathered the follower shards.
     unsigned long long nfollow8[8], nmed8[8];
     unsigned long long nbigcand;   // candidates longer than ENT_LONG columns: their entropy is counted by the whole grid
+    unsigned long long long_next, seg_next;  // k4_extend_long / k4_resolve_segments: next long hit / large segment to hand out
     unsigned long long nwalk_total, nwalk_over;  // walk-queue entries of the batch; fullest shard of any unit, in 1/1024 of its capacity (> 1024: overflow)
     unsigned long long dbg[8];  // development (MIMEO_K34_DEBUG & 8): why the pre-filter passed a hit on
 };
@@ -814,31 +815,88 @@ __device__ WalkResult wave_walk_fast(const StrandView &T, const StrandView &Q, i
     return r;
 }
 
-// full extension of one hit by one wavefront; emits candidate or follower record (lane 0)
-__device__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2 h, int xdrop, int hspthresh,
-                                 int transitions, bool detect, const ExtQueues &q, uint32_t unit, uint32_t *rext_out) {
+// full extension of one hit by one wavefront: what it leaves (valid in lane 0) — nothing, a follower record or a candidate
+struct HitRecord {
+    int kind;   // 0 nothing, 1 follower, 2 candidate
+    uint64_t fkey;
+    uint32_t fprev;
+    Cand c;
+};
+__device__ __forceinline__ HitRecord wave_extend_record(const StrandView &T, const StrandView &Q, uint2 h, int xdrop, int hspthresh,
+                                                        int transitions, bool detect, const ExtQueues &q, uint32_t unit, uint32_t *rext_out) {
+    HitRecord out;
+    out.kind = 0;
     const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN, d = (int32_t)h.x - (int32_t)h.y;
     WalkResult L = detect ? wave_walk(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop, true, transitions)
                           : wave_walk_fast(T, Q, et, d, -1, (uint32_t)min(et, eq), xdrop);
     if (L.found) {
-        if ((threadIdx.x & 63) == 0) {
-            unsigned long long i = atomicAdd(&q.ctr->nfollow8[queue_shard()], 1ull);
-            if (i < q.follow_cap) {
-                i += (unsigned long long)queue_shard() * q.follow_cap;
-                q.fkey[i] = follow_key(q, unit, d, Q.len, (uint32_t)et);
-                q.fprev[i] = L.prev_end;
-            }
-        }
-        return;
+        out.kind = 1;
+        out.fkey = follow_key(q, unit, d, Q.len, (uint32_t)et);
+        out.fprev = L.prev_end;
+        return out;
     }
     WalkResult R = wave_walk_fast(T, Q, et, d, +1, min(T.len - (uint32_t)et, Q.len - (uint32_t)eq), xdrop);
     if (rext_out) *rext_out = R.bsteps;
     int64_t score = L.best + R.best;
-    if (score >= hspthresh && (threadIdx.x & 63) == 0) {
+    if (score >= hspthresh) {
+        out.kind = 2;
+        out.c = Cand{(uint32_t)et - L.bsteps, (uint32_t)eq - L.bsteps, L.bsteps + R.bsteps,
+                     score >= (int64_t)RAW_SATURATED ? RAW_SATURATED : (int32_t)score, unit};  // k4_entropy recounts a saturated score
+    }
+    return out;
+}
+// A wavefront's records, kept in LDS until 16 are waiting: a same-address atomic takes ~13 ns, a C5 batch has 3 * 10^6 long
+// hits and as many large segments, and every one of them leaves records: one atomic per queue and 16 records instead
+constexpr uint32_t STAGE = 16;
+struct WaveStage {
+    Cand c[STAGE];
+    uint64_t fk[STAGE];
+    uint32_t fp[STAGE];
+};
+__device__ __forceinline__ void stage_flush(WaveStage &S, uint32_t &nf, uint32_t &nc, const ExtQueues &q) {
+    const uint32_t lane = threadIdx.x & 63u;
+    __builtin_amdgcn_wave_barrier();   // lane 0's records, read by the other lanes of this wavefront
+    if (nf) {
+        unsigned long long i = 0;
+        if (lane == 0) i = atomicAdd(&q.ctr->nfollow8[queue_shard()], (unsigned long long)nf);
+        i = __shfl(i, 0) + lane;
+        if (lane < nf && i < q.follow_cap) {
+            i += (unsigned long long)queue_shard() * q.follow_cap;
+            q.fkey[i] = S.fk[lane];
+            q.fprev[i] = S.fp[lane];
+        }
+    }
+    if (nc) {
+        unsigned long long i = 0;
+        if (lane == 0) i = atomicAdd(&q.ctr->ncand, (unsigned long long)nc);
+        i = __shfl(i, 0) + lane;
+        if (lane < nc && i < q.cand_cap) q.cand[i] = S.c[lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    nf = nc = 0;
+}
+__device__ __forceinline__ void stage_push(WaveStage &S, uint32_t &nf, uint32_t &nc, const HitRecord &r, const ExtQueues &q) {
+    const int kind = __builtin_amdgcn_readfirstlane(r.kind);
+    if (kind == 1) { if ((threadIdx.x & 63u) == 0) { S.fk[nf] = r.fkey; S.fp[nf] = r.fprev; } nf++; }
+    else if (kind == 2) { if ((threadIdx.x & 63u) == 0) S.c[nc] = r.c; nc++; }
+    if (nf == STAGE || nc == STAGE) stage_flush(S, nf, nc, q);
+}
+
+// ... or appended at once (lane 0)
+__device__ __forceinline__ void wave_extend_emit(const StrandView &T, const StrandView &Q, uint2 h, int xdrop, int hspthresh,
+                                                 int transitions, bool detect, const ExtQueues &q, uint32_t unit, uint32_t *rext_out) {
+    const HitRecord r = wave_extend_record(T, Q, h, xdrop, hspthresh, transitions, detect, q, unit, rext_out);
+    if ((threadIdx.x & 63) != 0) return;
+    if (r.kind == 1) {
+        unsigned long long i = atomicAdd(&q.ctr->nfollow8[queue_shard()], 1ull);
+        if (i < q.follow_cap) {
+            i += (unsigned long long)queue_shard() * q.follow_cap;
+            q.fkey[i] = r.fkey;
+            q.fprev[i] = r.fprev;
+        }
+    } else if (r.kind == 2) {
         unsigned long long i = atomicAdd(&q.ctr->ncand, 1ull);
-        if (i < q.cand_cap)
-            q.cand[i] = Cand{(uint32_t)et - L.bsteps, (uint32_t)eq - L.bsteps, L.bsteps + R.bsteps,
-                             score >= (int64_t)RAW_SATURATED ? RAW_SATURATED : (int32_t)score, unit};  // k4_entropy recounts a saturated score
+        if (i < q.cand_cap) q.cand[i] = r.c;
     }
 }
 

@@ -254,13 +254,26 @@ __global__ __launch_bounds__(256) void k4_walk_summary(const FusedUnit *__restri
 }
 
 // ---- long hits, one wavefront each ------------------------------------------------------------------------
+// (three wavefronts per SIMD fit its registers; the hits differ in length by orders of magnitude — a microsatellite diagonal
+// against a few hundred bases — so a wavefront takes the next 16 hits from a counter instead of a fixed stride; records: WaveStage)
+constexpr uint32_t CLAIM = 16;
 __global__ __launch_bounds__(EXT_THREADS) void k4_extend_long(const UnitDesc *__restrict__ units, ExtQueues q, int xdrop,
                                                               int hspthresh, int transitions) {
-    const uint64_t nlong = min((uint64_t)q.ctr->nlong, q.long_cap), nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
-    for (uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; wid < nlong; wid += nwaves) {
-        const uint32_t unit = q.longu[wid];
-        wave_extend_emit(units[unit].T, units[unit].Q, q.longq[wid], xdrop, hspthresh, transitions, true, q, unit, nullptr);
+    __shared__ WaveStage s_stage[EXT_THREADS / 64];
+    WaveStage &S = s_stage[threadIdx.x >> 6];
+    uint32_t nf = 0, nc = 0;
+    const uint64_t nlong = min((uint64_t)q.ctr->nlong, q.long_cap);
+    for (;;) {
+        unsigned long long w0 = 0;
+        if ((threadIdx.x & 63u) == 0) w0 = atomicAdd(&q.ctr->long_next, (unsigned long long)CLAIM);
+        w0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w0);
+        if (w0 >= nlong) break;
+        for (uint64_t wid = w0; wid < min(nlong, (uint64_t)w0 + CLAIM); wid++) {
+            const uint32_t unit = q.longu[wid];
+            stage_push(S, nf, nc, wave_extend_record(units[unit].T, units[unit].Q, q.longq[wid], xdrop, hspthresh, transitions, true, q, unit, nullptr), q);
+        }
     }
+    stage_flush(S, nf, nc, q);
 }
 
 // ---- the follower shards gathered into one array (input of the sort) ---------------------------------------------
@@ -362,8 +375,16 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(const UnitDes
                                                                    const uint64_t *__restrict__ nseg_dev,
                                                                    const uint64_t *__restrict__ list, int xdrop,
                                                                    int hspthresh, int transitions) {
-    const uint64_t nseg = *nseg_dev, nlist = q.ctr->nbig, nwaves = ((uint64_t)gridDim.x * EXT_THREADS) >> 6;
-    for (uint64_t wid = ((uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x) >> 6; wid < nlist; wid += nwaves) {
+    const uint64_t nseg = *nseg_dev, nlist = q.ctr->nbig;
+    __shared__ WaveStage s_stage[EXT_THREADS / 64];
+    WaveStage &S = s_stage[threadIdx.x >> 6];
+    uint32_t nf = 0, nc = 0;
+    for (;;) {   // segments differ in size by orders of magnitude: the next 16 from a counter
+    unsigned long long w0 = 0;
+    if ((threadIdx.x & 63) == 0) w0 = atomicAdd(&q.ctr->seg_next, (unsigned long long)CLAIM);
+    w0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w0);
+    if (w0 >= nlist) break;
+    for (uint64_t wid = w0; wid < min(nlist, (uint64_t)w0 + CLAIM); wid++) {
     const uint64_t sid = list[wid];
     uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
     uint64_t k0 = key[beg];
@@ -389,11 +410,13 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(const UnitDes
         if (prev[nxt] == RUN_END) et = max(key_end(q, key[nxt - 1]) + 1u, reach + 1u);   // the first member of the run beyond the reach
         uint2 h = make_uint2(et - SEED_LEN, (uint32_t)((int32_t)et - d) - SEED_LEN);
         uint32_t rext = 0;
-        wave_extend_emit(T, Q, h, xdrop, hspthresh, transitions, false, q, unit, &rext);
+        stage_push(S, nf, nc, wave_extend_record(T, Q, h, xdrop, hspthresh, transitions, false, q, unit, &rext), q);
         reach = et + rext;
         i = nxt;   // the same record again: a run may hold more members beyond the new reach (a plain record is passed by the search)
     }
     }
+    }
+    stage_flush(S, nf, nc, q);
 }
 
 // ---- the main diagonal of a strand aligned to itself ---------------------------------------------------------
@@ -690,10 +713,11 @@ uint64_t ExtBatch::arena_bytes() const {   // the queues proper: what the first 
     return cap_f_ * 8 * 12 + cap_m_ * 8 * 12 + cap_l_ * 12 + cap_c_ * (sizeof(Cand) + mf * (sizeof(mimeo_hsp) + 4)) + (v1_ ? 8 : walk_entries_ * 8) + 4096;
 }
 // ... plus what the rest of the batch may ask for while they are alive: the follower sort's second arena at its worst (every
-// shard full: 41 bytes per follower) and the chain / gapped stage's scratch and alignment slots (~200 bytes per HSP)
+// shard full: 41 bytes per follower) and the chain / gapped stage's scratch and alignment slots (~200 bytes per HSP, 60 more
+// where the chain stage meets large groups: k5_chain_wave's orders and tree)
 uint64_t ExtBatch::queue_bytes() const {
     const uint64_t mf = mirror_dst_.empty() ? 1 : 2;
-    return arena_bytes() + cap_f_ * 8 * 41 + cap_c_ * mf * 200;
+    return arena_bytes() + cap_f_ * 8 * 41 + cap_c_ * mf * 260;
 }
 // carve `bytes` (rounded up to 256) off an arena at *off
 static void *carve(const DeviceBuf &arena, size_t *off, size_t bytes) {
@@ -999,7 +1023,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         hipLaunchKernelGGL(k4_extend_generic, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh,
                            p->transitions, tab);
         if (!h_selfs.empty()) HIP_TRY(hipStreamWaitEvent(st, side_done, 0));
-        hipLaunchKernelGGL(k4_extend_long, dim3(256), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh, p->transitions);
+        hipLaunchKernelGGL(k4_extend_long, dim3(768), dim3(EXT_THREADS), 0, st, d_units, q, p->xdrop, p->hspthresh, p->transitions);
         HIP_TRY(hipMemcpyAsync(&c, ctr.p, sizeof c, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // round trip 1: follower count (sizes the sort), overflow check
         uint64_t nf = 0, nm = 0, maxf = 0, maxm = 0;
@@ -1048,7 +1072,7 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
                                (const uint64_t *)bigseg.p, p->xdrop, p->hspthresh, p->transitions);
         }
         if (!over) {
-            hipLaunchKernelGGL(k4_entropy, dim3(1024), dim3(EXT_THREADS), 0, st, d_units, q, p->hspthresh, p->entropy,
+            hipLaunchKernelGGL(k4_entropy, dim3(1536), dim3(EXT_THREADS), 0, st, d_units, q, p->hspthresh, p->entropy,
                                (mimeo_hsp *)hsps.p, (uint32_t *)hsp_unit.p);
             hipLaunchKernelGGL(k4_entropy_big, dim3(128, 16), dim3(256), 0, st, d_units, q);
             hipLaunchKernelGGL(k4_entropy_big_finish, dim3(16), dim3(256), 0, st, q, p->hspthresh, p->entropy, (mimeo_hsp *)hsps.p,

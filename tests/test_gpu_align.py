@@ -171,10 +171,11 @@ def test_long_extension_beyond_packed_counts(eng):
 
 def test_chain_with_tens_of_thousands_of_hsps(eng, monkeypatch):
     """K5 at a size where its structure matters: ~7e4 HSPs in ONE unit (a low hspthresh on an 800 kbp pair makes
-    nearly every strong seed hit an HSP): the two-level kernel for large groups (k5_chain_big: blocks of 2048 HSPs).
+    nearly every strong seed hit an HSP): the wave kernel for large groups (k5_chain_wave: a Fenwick tree over query ends).
     The chained subset — the alignments with gapped extension off — must equal the oracle's O(n^2) chain, and the
     anchor order (one stable device-wide sort by group, chained, score) must be the oracle's: score descending, then
-    (tstart, qstart, length).  The one-level kernel (MIMEO_K5_NO_BIG) must give the same."""
+    (tstart, qstart, length).  The one-level kernel (MIMEO_K5_NO_BIG) and the two-level kernel (MIMEO_K5_BIG=old: blocks of
+    2048 HSPs, the path of groups beyond 2^24 HSPs) must give the same."""
     from oracle import oracle as O
     names, seqs = synth_genome(66, 1_600_000, 2, repeat_frac=0.1, families=3, cons_len=(300, 3000), max_div=0.1)
     g = eng.Genome(names, seqs)
@@ -193,4 +194,38 @@ def test_chain_with_tens_of_thousands_of_hsps(eng, monkeypatch):
     one_level = eng.align_pair(g, 0, g, 1, eng.default_params(gapped=0, strand=1, hspthresh=1150, entropy=0))
     monkeypatch.delenv('MIMEO_K5_NO_BIG')
     assert one_level.tobytes() == got.tobytes()
+    monkeypatch.setenv('MIMEO_K5_BIG', 'old')
+    two_level = eng.align_pair(g, 0, g, 1, eng.default_params(gapped=0, strand=1, hspthresh=1150, entropy=0))
+    monkeypatch.delenv('MIMEO_K5_BIG')
+    assert two_level.tobytes() == got.tobytes()
+    g.close()
+
+
+def test_wave_chain_on_every_group_size(eng, monkeypatch):
+    """MIMEO_K5_BIG_MIN=1 sends every group with two or more HSPs through the wave kernel: groups of a few HSPs (tiles only),
+    collinear runs (every HSP a step's predecessor), tandem arrays and microsatellite rectangles (waves of many HSPs that
+    start together) — chained subsets and alignments against the oracle, both strands."""
+    from oracle import oracle as O
+    monkeypatch.setenv('MIMEO_K5_BIG_MIN', '1')
+    names, seqs = synth_genome(93, 900_000, 3, repeat_frac=0.3, families=3, cons_len=(200, 2500), max_div=0.2, indel_rate=0.02, microsat_frac=0.02)
+    g = eng.Genome(names, seqs)
+    nchained = 0
+    for t, q in ((0, 1), (1, 2), (2, 2)):
+        for strand, sbit in ((0, 1), (1, 2)):
+            got = eng.align_pair(g, t, g, q, eng.default_params(gapped=0, strand=sbit, hspthresh=2000))
+            exp = O.ungapped_hsps(seqs[t].tobytes(), seqs[q].tobytes(), strand, O.default_params(hspthresh=2000))
+            exp = exp[(exp['flags'] & 1) == 1]
+            e = exp[np.lexsort((exp['length'], exp['qstart'], exp['tstart'], -exp['score']))]
+            assert got.size == e.size, (t, q, strand, got.size, e.size)
+            assert np.array_equal(got['tstart'], e['tstart']) and np.array_equal(got['score'], e['score']) and np.array_equal(got['tend'] - got['tstart'], e['length'])
+            nchained += e.size
+    assert nchained > 100
+    pairs = [(t, q) for t in range(3) for q in range(3)]
+    got = eng.align_pairs(g, None, pairs)
+    exp_all = []
+    for t, q in pairs:
+        e = O.align_pair(seqs[t].tobytes(), seqs[q].tobytes())
+        e['tid'], e['qid'] = t, q
+        exp_all.append(e)
+    _cmp(got, np.concatenate(exp_all), 'wave-all', ordered=True)
     g.close()
