@@ -225,6 +225,14 @@ int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome 
                         uint32_t qstrand, const mimeo_params *p, mimeo_hsp **out, uint64_t *nout);
 
 /*
+ * lastz --chain alone (A9; wrappers.py:1031), a stage inside lastz exposed for parity tests like the two above:
+ * the n HSPs of ONE (target, query, strand) are copied to out[0 .. n) in (tstart, qstart, length) order with bit 0
+ * of `flags` set on the members of the best chain (ties: earliest predecessor, earliest end) and cleared on the
+ * others.  Runs K5 as mimeo_align_pairs does (the kernel is chosen by the number of HSPs).  out: n records, the caller's.
+ */
+int mimeo_chain_hsps(const mimeo_hsp *in, uint64_t n, mimeo_hsp *out);
+
+/*
  * One full `lastz t.fa q.fa ...` invocation (A6-A10; wrappers.py:1025-1037): all
  * requested strands of one (target, query) pair -> gapped alignments.
  */

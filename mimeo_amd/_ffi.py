@@ -18,7 +18,7 @@ SYMBOLS = [
     'mimeo_genome_length', 'mimeo_seed_hits', 'mimeo_ungapped_hsps', 'mimeo_align_pair', 'mimeo_align_pairs',
     'mimeo_coverage_collapse', 'mimeo_tandem_masked', 'mimeo_genome_load_fasta', 'mimeo_genome_name',
     'mimeo_genome_keep_indexes', 'mimeo_genome_drop_indexes', 'mimeo_genome_build_indexes', 'mimeo_coverage_bedgraph',
-    'mimeo_align_units', 'mimeo_get_failed_pairs',
+    'mimeo_align_units', 'mimeo_get_failed_pairs', 'mimeo_chain_hsps',
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     if hasattr(lib, 'mimeo_align_units'):
         lib.mimeo_align_units.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]
         lib.mimeo_get_failed_pairs.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    if hasattr(lib, 'mimeo_chain_hsps'):
+        lib.mimeo_chain_hsps.argtypes = [vp, u64, vp]
     if hasattr(lib, 'mimeo_coverage_collapse'):
         lib.mimeo_coverage_collapse.argtypes = [vp, u64, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(u64)]
     if hasattr(lib, 'mimeo_coverage_bedgraph'):

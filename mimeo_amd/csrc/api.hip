@@ -248,6 +248,34 @@ int mimeo_seed_hits(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, 
     return rc;
 }
 
+int mimeo_chain_hsps(const mimeo_hsp *in, uint64_t n, mimeo_hsp *out) {
+    int rc = need_init();
+    if (rc) return rc;
+    if (!n) return 0;
+    if (!in || !out) { set_error("mimeo_chain_hsps: null argument"); return MIMEO_ERR_ARG; }
+    if (n >= (1ull << 32)) { set_error("more than 2^32 HSPs"); return MIMEO_ERR_LIMIT; }
+    DeviceBuf d_in, d_unit, d_group, d_sorted, d_best, d_cand, d_pred, d_order;
+    auto done = [&](int r) {
+        d_in.release(); d_unit.release(); d_group.release(); d_sorted.release(); d_best.release(); d_cand.release(); d_pred.release(); d_order.release();
+        return r;
+    };
+    if ((rc = d_in.reserve(n * sizeof(mimeo_hsp))) || (rc = d_unit.reserve(n * 4)) || (rc = d_group.reserve(sizeof(Group))) ||
+        (rc = d_sorted.reserve(n * sizeof(mimeo_hsp))) || (rc = d_best.reserve(n * 8)) || (rc = d_cand.reserve(n * 8)) ||
+        (rc = d_pred.reserve(n * 4)) || (rc = d_order.reserve(n * 4)))
+        return done(rc);
+    hipError_t e = hipMemcpy(d_in.p, in, n * sizeof(mimeo_hsp), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_unit.p, 0, n * 4);
+    if (e == hipSuccess) e = hipMemset(d_group.p, 0, sizeof(Group));
+    if (e != hipSuccess) return done(hip_fail(e, "mimeo_chain_hsps: upload", __FILE__, __LINE__));
+    if ((rc = chain_device((Group *)d_group.p, 1, (const mimeo_hsp *)d_in.p, (const uint32_t *)d_unit.p, n, 1, (mimeo_hsp *)d_sorted.p,
+                           (long long *)d_best.p, (long long *)d_cand.p, (int *)d_pred.p, (uint32_t *)d_order.p)))
+        return done(rc);
+    e = hipStreamSynchronize(stream());
+    if (e == hipSuccess) e = hipMemcpy(out, d_sorted.p, n * sizeof(mimeo_hsp), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(hip_fail(e, "mimeo_chain_hsps: download", __FILE__, __LINE__));
+    return done(0);
+}
+
 int mimeo_ungapped_hsps(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q, uint32_t qid, uint32_t qstrand,
                         const mimeo_params *p, mimeo_hsp **out, uint64_t *nout) {
     int rc = check_pair(T, tid, Q, qid, p, out, nout);

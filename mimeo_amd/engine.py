@@ -123,6 +123,15 @@ def ungapped_hsps(T, tid, Q, qid, qstrand=0, params=None):
     return _ffi.take(ptr, n, _ffi.HSP)
 
 
+def chain_hsps(hsps):
+    """lastz --chain on the HSPs of one (target, query, strand): the HSPs in (tstart, qstart, length) order, bit 0 of
+    `flags` set on the members of the chain (include/mimeo_hip.h: mimeo_chain_hsps; a test entry like ungapped_hsps)."""
+    h = np.ascontiguousarray(hsps, dtype=_ffi.HSP)
+    out = np.zeros(h.size, dtype=_ffi.HSP)
+    _ffi.check(_ffi.load().mimeo_chain_hsps(h.ctypes.data, h.size, out.ctypes.data))
+    return out
+
+
 def align_pair(T, tid, Q, qid, params=None):
     p = params or default_params()
     ptr, n = C.c_void_p(), C.c_uint64()

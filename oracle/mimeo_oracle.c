@@ -505,6 +505,9 @@ int orc_ungapped_hsps(const uint8_t *Ta, uint64_t Lt, const uint8_t *Qa, uint64_
 }
 
 /* A6-A10: one `lastz T Q` run; rows in (strand, discovery) order. */
+/* the chain stage alone on caller-made HSPs of one (target, query, strand): sorted in place, bit 0 of flags = chained */
+int orc_chain_hsps(orc_hsp *h, uint64_t n) { return chain_hsps(h, n); }
+
 int orc_align_pair(const uint8_t *Ta, uint64_t Lt, const uint8_t *Qa, uint64_t Lq,
                    const orc_params *p, orc_aln **out, uint64_t *nout) {
     alnvec av = {0, 0, 0};

@@ -107,6 +107,14 @@ def ungapped_hsps(T, Q, minus=0, params=None):
     return _take(ptr, n, HSP)
 
 
+def chain_hsps(hsps):
+    """the chain stage alone (mimeo_oracle.c: chain_hsps, O(n^2)): the HSPs sorted by (tstart, qstart, length), flags bit 0 = chained"""
+    h = np.ascontiguousarray(hsps, dtype=HSP).copy()
+    rc = lib().orc_chain_hsps(h.ctypes.data_as(C.c_void_p), C.c_uint64(h.size))
+    assert rc == 0
+    return h
+
+
 def align_pair(T, Q, params=None):
     p = params or default_params()
     ptr, n = C.c_void_p(), C.c_uint64()
