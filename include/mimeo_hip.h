@@ -255,7 +255,7 @@ int mimeo_align_pair(const mimeo_genome *T, uint32_t tid, const mimeo_genome *Q,
  * DESIGN.md "Fragmented assemblies"); in a self job (B == NULL) the plus-strand units of (t, q) and
  * (q, t) share one seed scan and gap-free stage when neither scaffold has soft-masked bases (DESIGN.md
  * "Shared plus strand").  Limits: scaffolds below 2^31 - 256 bases.  A pair whose gapped extension
- * scores beyond 2^31 or needs a DP band beyond 65 536 columns is LEFT OUT — no row of it is returned,
+ * needs a DP band beyond 65 536 columns is LEFT OUT — no row of it is returned,
  * the other pairs are, the call returns 0 and mimeo_get_failed_pairs names the pair: the reference's
  * run_jobs.sh has no `set -e`, a failing lastz run costs its own pair's rows only (utils.py:125-128,
  * :194-210 look at the last command's status).

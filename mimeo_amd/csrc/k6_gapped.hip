@@ -40,6 +40,7 @@ struct HalfResult {
     int32_t score;
     uint32_t i, j, nm, nx, overflow;
     uint32_t maxcols, rows;  // widest live band (columns from the window base) and rows evaluated: tuning statistics
+    uint32_t base_lo, base_hi;  // k6_dp_any: what its rebased 32-bit cells stand above (score = base + score), 0 elsewhere
 };
 struct DpJob {
     uint32_t group, at, aq;
@@ -49,7 +50,8 @@ struct DpJob {
 
 // score of a half extension: the identical-suffix shortcut (rows == 0, i > 0) carries 64 bits
 __device__ __forceinline__ int64_t half_score(const HalfResult &r) {
-    return (r.rows == 0 && r.i > 0) ? (int64_t)(((uint64_t)r.maxcols << 32) | (uint32_t)r.score) : (int64_t)r.score;
+    return (r.rows == 0 && r.i > 0) ? (int64_t)(((uint64_t)r.maxcols << 32) | (uint32_t)r.score)
+                                    : (int64_t)r.score + (int64_t)(((uint64_t)r.base_hi << 32) | r.base_lo);
 }
 
 __device__ __forceinline__ Cell cmax_left(const Cell &l, const Cell &r) { return r.s > l.s ? r : l; }  // ties -> left
@@ -139,7 +141,7 @@ __device__ __forceinline__ RowBases load_row_bases(const StrandView &T, uint32_t
 
 template <int WSTRIP>
 __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q, uint32_t at, uint32_t aq, int dir,
-                                       int32_t O, int32_t E, int32_t Y) {
+                                       int32_t O, int32_t E, int32_t Y, int32_t cap) {
     constexpr int WINDOW = 64 * WSTRIP;  // columns in the sliding window
     constexpr int WSHIFT = WSTRIP == 32 ? 5 : 4;
     static_assert((1 << WSHIFT) == WSTRIP, "WSTRIP must be 16 or 32");
@@ -260,6 +262,9 @@ __device__ HalfResult wave_half_extend(const StrandView &T, const StrandView &Q,
         if (__ballot(rb.s > best.score)) {
             const Best4 t = wave_best(rb);
             if (t.s > best.score) { best.score = t.s; best.i = i; best.j = t.j; best.nm = t.nm; best.nx = t.nx; }
+            // 32-bit cells and no limit on the rows here: a half extension that nears 2^31 (20 Mbp of near-identity without a
+            // break) goes on to k6_dp_any, which rebases its cells
+            if (best.score > cap) { best.overflow = 1; break; }
         }
         // slide the window so that it starts at the strip holding the first live column
         const uint32_t fmask = (uint32_t)__builtin_amdgcn_readlane((int)amask, (int)rf);
@@ -942,22 +947,22 @@ __global__ __launch_bounds__(64) void k6_pick(Group *__restrict__ groups, const 
 
 __global__ __launch_bounds__(64) void k6_dp(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                             HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y,
-                                            int only_overflowed) {
+                                            int only_overflowed, int32_t cap) {
     const DpJob job = jobs[blockIdx.x];
     if (only_overflowed && !res[job.slot].overflow) return;
     const Group &G = groups[job.group];
-    HalfResult r = wave_half_extend<16>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    HalfResult r = wave_half_extend<16>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y, cap);
     if (threadIdx.x == 0) res[job.slot] = r;
 }
 
 // second chance for half extensions whose band outgrew the 1024-column window: 2048 columns
 __global__ __launch_bounds__(64) void k6_dp_wide(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                                  HalfResult *__restrict__ res, int32_t O, int32_t E, int32_t Y,
-                                                 unsigned int *__restrict__ novf, unsigned int *__restrict__ ovf_list) {
+                                                 unsigned int *__restrict__ novf, unsigned int *__restrict__ ovf_list, int32_t cap) {
     const DpJob job = jobs[blockIdx.x];
     if (!res[job.slot].overflow) return;
     const Group &G = groups[job.group];
-    HalfResult r = wave_half_extend<32>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y);
+    HalfResult r = wave_half_extend<32>(G.T, G.Q, job.at, job.aq, job.dir, O, E, Y, cap);
     if (threadIdx.x == 0) {
         res[job.slot] = r;
         if (r.overflow) ovf_list[atomicAdd(novf, 1u)] = blockIdx.x;  // band beyond 2048 columns: k6_dp_any
@@ -984,7 +989,7 @@ constexpr size_t ANY_SLOT_WORDS = 2u * 6u * (size_t)ANY_COLS;  // per job
 __global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict__ groups, const DpJob *__restrict__ jobs,
                                                          const unsigned int *__restrict__ list, uint32_t first,
                                                          HalfResult *__restrict__ res, uint32_t *__restrict__ scratch,
-                                                         int32_t O, int32_t E, int32_t Y) {
+                                                         int32_t O, int32_t E, int32_t Y, int32_t cap) {
     __shared__ Cell s_scan[ANY_THREADS / 64];
     __shared__ Best4 s_best[ANY_THREADS / 64];
     __shared__ uint32_t s_first[ANY_THREADS / 64], s_last[ANY_THREADS / 64];
@@ -997,7 +1002,8 @@ __global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict
     const uint32_t lenA = dir > 0 ? T.len - at : at, lenB = dir > 0 ? Q.len - aq : aq;
     uint32_t *base = scratch + (size_t)blockIdx.x * ANY_SLOT_WORDS;
     const uint32_t M = ANY_COLS - 1u;
-    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0};
+    HalfResult best{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long sbase = 0;   // the cells are 32 bits wide and stand above this (below)
     // row 0: C(0,j) = -O - j*E while that is within the y-drop
     uint32_t lo = 0, hi = 0;
     if (Y >= O + E) hi = min(lenB, (uint32_t)((Y - O) / E));
@@ -1098,10 +1104,23 @@ __global__ __launch_bounds__(ANY_THREADS) void k6_dp_any(const Group *__restrict
         best.maxcols = max(best.maxcols, hi - lo + 1u);
         best.rows = i;
         if (tb.s > best.score) { best.score = tb.s; best.i = i; best.j = tb.j; best.nm = tb.nm; best.nx = tb.nx; }
-        // the cells are 32 bits wide (as lastz's own score_t): a half extension that nears 2^31 — 20 Mbp of near-identity without a
-        // break — is refused before it wraps; its pair is left out and named (mimeo_get_failed_pairs)
-        if (best.score > 2000000000) { overflow = true; break; }
+        // The cells are 32 bits wide (as lastz's own score_t, which wraps there).  Every live cell of a row lies within the
+        // y-drop of the best score so far, so when that nears the cap the whole row — and the best score — is moved down by
+        // half the cap and `sbase` up: comparisons inside a row and between neighbouring rows never see the difference, and
+        // the half's score is sbase + best.score in 64 bits
+        if (best.score > cap) {
+            const int32_t K = cap / 2;
+            for (uint32_t j = lo + tid; j <= hi; j += ANY_THREADS) {
+                if (N.cs[j & M] > NEGH) N.cs[j & M] -= K;
+                if (N.ds[j & M] > NEGH) N.ds[j & M] -= K;
+            }
+            best.score -= K;
+            sbase += K;
+            __syncthreads();
+        }
     }
+    best.base_lo = (uint32_t)(unsigned long long)sbase;
+    best.base_hi = (uint32_t)((unsigned long long)sbase >> 32);
     best.overflow = overflow ? 1u : 0u;
     if (tid == 0) res[job.slot] = best;
 }
@@ -1255,6 +1274,9 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
         if (getenv("MIMEO_K6_BMAX")) bmax = (uint32_t)atoi(getenv("MIMEO_K6_BMAX"));
         const char *kmode = getenv("MIMEO_K6_KERNEL");       // development switches: read once per call, not per round
         const bool k6_stats = getenv("MIMEO_K6_STATS") != nullptr;
+        // 32-bit DP cells: beyond this score a half extension goes to (or, in k6_dp_any, rebases its cells in) the last kernel;
+        // MIMEO_K6_SCORE_CAP lowers it so that tests of ordinary size take that road
+        const int32_t cap = getenv("MIMEO_K6_SCORE_CAP") ? std::max(100000, atoi(getenv("MIMEO_K6_SCORE_CAP"))) : 2000000000;
         bmax = bmax < 1 ? 1 : (bmax > MAX_BATCH ? MAX_BATCH : bmax);
         if ((rc = g_anchors.reserve(nhsps * sizeof(uint2)))) return rc;
         if ((rc = g_packed.reserve(nhsps * 8))) return rc;
@@ -1294,11 +1316,11 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                         hipLaunchKernelGGL(k6_dp4, dim3(h[0]), dim3(C4_THREADS), 0, st, (const Group *)d_groups,
                                            (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop);
                     hipLaunchKernelGGL(k6_dp, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups, (const DpJob *)g_jobs.p,
-                                       (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0);
+                                       (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, use4 ? 1 : 0, cap);
                 }
                 hipLaunchKernelGGL(k6_dp_wide, dim3(h[0]), dim3(64), 0, st, (const Group *)d_groups,
                                    (const DpJob *)g_jobs.p, (HalfResult *)g_res.p, p->gap_open, p->gap_extend, p->ydrop, novf,
-                                   (unsigned int *)g_ovf_list.p);
+                                   (unsigned int *)g_ovf_list.p, cap);
                 // bands beyond 2048 columns (tandem arrays): the global-memory kernel, a few jobs at a time
                 unsigned int nov = 0;
                 HIP_TRY(hipMemcpyAsync(&nov, novf, 4, hipMemcpyDeviceToHost, st));
@@ -1309,7 +1331,7 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                     for (unsigned int f = 0; f < nov; f += slots)
                         hipLaunchKernelGGL(k6_dp_any, dim3(std::min(slots, nov - f)), dim3(ANY_THREADS), 0, st, (const Group *)d_groups,
                                            (const DpJob *)g_jobs.p, (const unsigned int *)g_ovf_list.p, f, (HalfResult *)g_res.p,
-                                           (uint32_t *)g_any.p, p->gap_open, p->gap_extend, p->ydrop);
+                                           (uint32_t *)g_any.p, p->gap_open, p->gap_extend, p->ydrop, cap);
                 }
             }
             if (k6_stats && h[0]) {
@@ -1324,7 +1346,9 @@ int gapped_device(Group *d_groups, uint32_t ngroups, const mimeo_hsp *d_sorted, 
                     if (!r.rows) { shortcut++; continue; }
                     hist[std::min<uint32_t>(8, r.maxcols / 128)]++; rows += r.rows; maxr = std::max<unsigned long long>(maxr, r.rows);
                 }
-                fprintf(stderr, "[k6] jobs %u shortcut %llu rows total %llu max %llu band<128..>=1024:", h[0], shortcut, rows, maxr);
+                unsigned long long rebased = 0;
+                for (auto &r : hr) if (r.base_lo | r.base_hi) rebased++;
+                fprintf(stderr, "[k6] jobs %u shortcut %llu (rebased in k6_dp_any: %llu) rows total %llu max %llu band<128..>=1024:", h[0], shortcut, rebased, rows, maxr);
                 for (int b = 0; b < 9; b++) fprintf(stderr, " %llu", hist[b]);
                 fprintf(stderr, "\n");
                 {

@@ -174,8 +174,8 @@ static void record_failure(uint64_t pair, uint32_t tid, uint32_t qid, char stran
     failed[pair] = 1;
     g_failed.emplace_back(pair, MIMEO_ERR_LIMIT);
     char msg[256];
-    snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns, or score beyond "
-             "int32: not supported; the pair is left out (mimeo_get_failed_pairs)", tid, qid, strand);
+    snprintf(msg, sizeof msg, "gapped extension of target %u, query %u, strand %c: DP band wider than 65536 columns: "
+             "not supported; the pair is left out (mimeo_get_failed_pairs)", tid, qid, strand);
     set_error(msg);   // readable through mimeo_last_error() although the call succeeds
 }
 

@@ -145,11 +145,18 @@ def test_tandem_arrays_default_parameters(eng):
     g.close()
 
 
-def test_long_extension_beyond_packed_counts(eng):
+@pytest.mark.parametrize('cap', [None, '100000'])
+def test_long_extension_beyond_packed_counts(eng, monkeypatch, cap):
     """A 300 kb alignment with 3 % substitutions and a few indels: each half extension runs for more than
     65535 rows, past what the packed match/mismatch counters of the four-wavefront DP kernel hold, so the
-    single-wavefront kernel must take over — same alignment, same identity counts as the oracle."""
+    single-wavefront kernel must take over — same alignment, same identity counts as the oracle.
+
+    cap = 100000: the score beyond which the 2048-column kernel hands a half extension to k6_dp_any, and beyond which that
+    kernel moves its 32-bit cells down (2 * 10^9 in production: 20 Mbp of near-identity in one alignment; the oracle
+    scores in 64 bits).  Here every half extension of the long alignment is rebased some 250 times: same alignment."""
     from oracle import oracle as O
+    if cap:
+        monkeypatch.setenv('MIMEO_K6_SCORE_CAP', cap)
     rng = np.random.default_rng(123)
     acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
     core = rng.integers(0, 4, 300_000)
