@@ -47,77 +47,140 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_extend_generic(const UnitDesc 
         for (int r = 0; r < 8; r++) { acc += min((uint64_t)q.ctr->nmed8[r], q.med_cap); sh_end[r] = acc; }
     }
     const uint64_t nhits = sh_end[7];
-    for (uint64_t gid = (uint64_t)blockIdx.x * EXT_THREADS + threadIdx.x; gid < nhits;
-         gid += (uint64_t)gridDim.x * EXT_THREADS) {
-        uint32_t r = 0;
+    // What a hit leaves — a follower record, a place in the long queue or a candidate — waits in LDS until the wavefront has 64
+    // of a kind: appended lane by lane where the walks end, these were three same-address atomics per wavefront and step
+    // (~13 ns each: the duration of this kernel on a batch with 3 * 10^7 such hits)
+    constexpr uint32_t GCAP = 64;
+    __shared__ uint64_t s_fk[EXT_THREADS / 64][GCAP];
+    __shared__ uint32_t s_fp[EXT_THREADS / 64][GCAP];
+    __shared__ uint2 s_lh[EXT_THREADS / 64][GCAP];
+    __shared__ uint32_t s_lu[EXT_THREADS / 64][GCAP];
+    __shared__ Cand s_cd[EXT_THREADS / 64][GCAP];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_fol = 0, n_long = 0, n_cd = 0;   // wave-uniform
+    auto flush_fol = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&q.ctr->nfollow8[queue_shard()], (unsigned long long)n_fol);
+        b = __shfl(b, 0) + lane;
+        if (lane < n_fol && b < q.follow_cap) { const size_t at = (size_t)queue_shard() * q.follow_cap + b; q.fkey[at] = s_fk[wv][lane]; q.fprev[at] = s_fp[wv][lane]; }
+        n_fol = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_long = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&q.ctr->nlong, (unsigned long long)n_long);
+        b = __shfl(b, 0) + lane;
+        if (lane < n_long && b < q.long_cap) { q.longq[b] = s_lh[wv][lane]; q.longu[b] = s_lu[wv][lane]; }
+        n_long = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_cd = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&q.ctr->ncand, (unsigned long long)n_cd);
+        b = __shfl(b, 0) + lane;
+        if (lane < n_cd && b < q.cand_cap) q.cand[b] = s_cd[wv][lane];
+        n_cd = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    const uint64_t stride = (uint64_t)gridDim.x * EXT_THREADS;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * EXT_THREADS + wv * 64u; g0 < nhits; g0 += stride) {   // wave-uniform bound
+        const uint64_t gid = g0 + lane;
+        bool o_fol = false, o_long = false, o_cd = false;
+        uint64_t r_fk = 0;
+        uint32_t r_fp = 0, unit = 0;
+        uint2 h = make_uint2(0, 0);
+        Cand r_cd{0, 0, 0, 0, 0};
+        if (gid < nhits) {
+            uint32_t r = 0;
 #pragma unroll
-        for (int k = 0; k < 7; k++) r += gid >= sh_end[k] ? 1u : 0u;
-        const uint64_t at = (uint64_t)r * q.med_cap + (gid - (r ? sh_end[r - 1] : 0));
-        const uint2 h = q.medq[at];
-        const uint32_t unit = q.medu[at];
-        const StrandView T = units[unit].T, Q = units[unit].Q;
-        const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
-        const int32_t d = (int32_t)h.x - (int32_t)h.y;
-        // ---- left walk, with detection of an earlier seed hit at every reached boundary
-        WalkState L{0, 0, 0, 0, false, false, 0};
-        const uint32_t maxl = (uint32_t)min(et, eq);
-        bool is_long = false;
-        for (int win = 0; !L.done; win++) {
-            if (win == LONG_WINDOWS) { is_long = true; break; }
-            const int32_t P = et - 32 * (win + 1) - SEED_LEN, Pq = P - d;
-            const Win64 tw = win64(T, P), qw = win64(Q, Pq);
-            const uint64_t dl64 = tw.lo ^ qw.lo, dh64 = tw.hi ^ qw.hi, nm64 = dl64 | dh64;
-            const uint32_t nlo = (uint32_t)nm64, nhi = (uint32_t)(nm64 >> 32);
-            const uint32_t tlo = (uint32_t)dl64, thi = (uint32_t)(dl64 >> 32);
-            // seed hits among the 32 starts P .. P+31: care positions carry at most one non-match,
-            // and it must be a transition (dl = 0)
-            uint32_t ones = 0, twos = 0, tv = 0;
-#pragma unroll
-            for (int c = 0; c < SEED_LEN; c++) {
-                if (!((CARE19 >> c) & 1u)) continue;
-                const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
-                twos |= ones & v;
-                ones |= v;
-                tv |= c ? __builtin_amdgcn_alignbit(thi, tlo, c) : tlo;
-            }
-            const uint32_t bad = transitions ? (twos | tv) : ones;
-            const uint32_t H = ~bad & seedvalid32(T, P, (uint32_t)tw.sv) & (uint32_t)qw.sv;
-            // walk bits in step order: step s <-> position P + 19 + 31 - s
-            walk_window(tab, L, __brev((uint32_t)(dl64 >> SEED_LEN)), __brev((uint32_t)(dh64 >> SEED_LEN)),
-                        __brev((uint32_t)((tw.lo ^ tw.hi) >> SEED_LEN)), __brev((uint32_t)((tw.nm | qw.nm) >> SEED_LEN)),
-                        __brev(H), maxl, xdrop);
-        }
-        if (!is_long && L.found) {
-            unsigned long long i = wave_slot(&q.ctr->nfollow8[queue_shard()]);   // one atomic for the lanes that are here together
-            if (i < q.follow_cap) {
-                i += (unsigned long long)queue_shard() * q.follow_cap;
-                q.fkey[i] = follow_key(q, unit, d, Q.len, (uint32_t)et);
-                q.fprev[i] = (uint32_t)et - L.found_step;  // position of the base just summed = that seed's end
-            }
-            continue;
-        }
-        // ---- right walk
-        WalkState R{0, 0, 0, 0, false, false, 0};
-        if (!is_long) {
-            const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
-            for (int win = 0; !R.done; win++) {
+            for (int k = 0; k < 7; k++) r += gid >= sh_end[k] ? 1u : 0u;
+            const uint64_t at = (uint64_t)r * q.med_cap + (gid - (r ? sh_end[r - 1] : 0));
+            h = q.medq[at];
+            unit = q.medu[at];
+            const StrandView T = units[unit].T, Q = units[unit].Q;
+            const int32_t et = (int32_t)h.x + SEED_LEN, eq = (int32_t)h.y + SEED_LEN;
+            const int32_t d = (int32_t)h.x - (int32_t)h.y;
+            // ---- left walk, with detection of an earlier seed hit at every reached boundary
+            WalkState L{0, 0, 0, 0, false, false, 0};
+            const uint32_t maxl = (uint32_t)min(et, eq);
+            bool is_long = false;
+            for (int win = 0; !L.done; win++) {
                 if (win == LONG_WINDOWS) { is_long = true; break; }
-                const int32_t P = et + 32 * win, Pq = P - d;
-                const Win32 tw = win32(T, P), qw = win32(Q, Pq);
-                walk_window(tab, R, tw.lo ^ qw.lo, tw.hi ^ qw.hi, tw.lo ^ tw.hi, tw.nm | qw.nm, 0u, maxr, xdrop);
+                const int32_t P = et - 32 * (win + 1) - SEED_LEN, Pq = P - d;
+                const Win64 tw = win64(T, P), qw = win64(Q, Pq);
+                const uint64_t dl64 = tw.lo ^ qw.lo, dh64 = tw.hi ^ qw.hi, nm64 = dl64 | dh64;
+                const uint32_t nlo = (uint32_t)nm64, nhi = (uint32_t)(nm64 >> 32);
+                const uint32_t tlo = (uint32_t)dl64, thi = (uint32_t)(dl64 >> 32);
+                // seed hits among the 32 starts P .. P+31: care positions carry at most one non-match,
+                // and it must be a transition (dl = 0)
+                uint32_t ones = 0, twos = 0, tv = 0;
+#pragma unroll
+                for (int c = 0; c < SEED_LEN; c++) {
+                    if (!((CARE19 >> c) & 1u)) continue;
+                    const uint32_t v = c ? __builtin_amdgcn_alignbit(nhi, nlo, c) : nlo;
+                    twos |= ones & v;
+                    ones |= v;
+                    tv |= c ? __builtin_amdgcn_alignbit(thi, tlo, c) : tlo;
+                }
+                const uint32_t bad = transitions ? (twos | tv) : ones;
+                const uint32_t H = ~bad & seedvalid32(T, P, (uint32_t)tw.sv) & (uint32_t)qw.sv;
+                // walk bits in step order: step s <-> position P + 19 + 31 - s
+                walk_window(tab, L, __brev((uint32_t)(dl64 >> SEED_LEN)), __brev((uint32_t)(dh64 >> SEED_LEN)),
+                            __brev((uint32_t)((tw.lo ^ tw.hi) >> SEED_LEN)), __brev((uint32_t)((tw.nm | qw.nm) >> SEED_LEN)),
+                            __brev(H), maxl, xdrop);
+            }
+            if (!is_long && L.found) {
+                o_fol = true;
+                r_fk = follow_key(q, unit, d, Q.len, (uint32_t)et);
+                r_fp = (uint32_t)et - L.found_step;  // position of the base just summed = that seed's end
+            } else {
+                // ---- right walk
+                WalkState R{0, 0, 0, 0, false, false, 0};
+                if (!is_long) {
+                    const uint32_t maxr = min(T.len - (uint32_t)et, Q.len - (uint32_t)eq);
+                    for (int win = 0; !R.done; win++) {
+                        if (win == LONG_WINDOWS) { is_long = true; break; }
+                        const int32_t P = et + 32 * win, Pq = P - d;
+                        const Win32 tw = win32(T, P), qw = win32(Q, Pq);
+                        walk_window(tab, R, tw.lo ^ qw.lo, tw.hi ^ qw.hi, tw.lo ^ tw.hi, tw.nm | qw.nm, 0u, maxr, xdrop);
+                    }
+                }
+                if (is_long) o_long = true;
+                else {
+                    const int32_t score = L.best + R.best;
+                    if (score >= hspthresh) { o_cd = true; r_cd = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, score, unit}; }
+                }
             }
         }
-        if (is_long) {
-            const unsigned long long i = wave_slot(&q.ctr->nlong);
-            if (i < q.long_cap) { q.longq[i] = h; q.longu[i] = unit; }
-            continue;
+        uint64_t m = __ballot(o_fol);
+        if (m) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_fol + add > GCAP) flush_fol();
+            if (o_fol) { const uint32_t i = n_fol + (uint32_t)__popcll(m & lt_mask); s_fk[wv][i] = r_fk; s_fp[wv][i] = r_fp; }
+            n_fol += add;
         }
-        const int32_t score = L.best + R.best;
-        if (score >= hspthresh) {
-            const unsigned long long i = wave_slot(&q.ctr->ncand);
-            if (i < q.cand_cap) q.cand[i] = Cand{(uint32_t)et - L.bk, (uint32_t)eq - L.bk, L.bk + R.bk, score, unit};
+        m = __ballot(o_long);
+        if (m) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_long + add > GCAP) flush_long();
+            if (o_long) { const uint32_t i = n_long + (uint32_t)__popcll(m & lt_mask); s_lh[wv][i] = h; s_lu[wv][i] = unit; }
+            n_long += add;
+        }
+        m = __ballot(o_cd);
+        if (m) {
+            const uint32_t add = (uint32_t)__popcll(m);
+            if (n_cd + add > GCAP) flush_cd();
+            if (o_cd) s_cd[wv][n_cd + (uint32_t)__popcll(m & lt_mask)] = r_cd;
+            n_cd += add;
         }
     }
+    if (n_fol) flush_fol();
+    if (n_long) flush_long();
+    if (n_cd) flush_cd();
 }
 
 // ---- heavy kernel of the A/B path: the hit array of the stand-alone K3 join, one lane per hit ----------------
@@ -463,9 +526,27 @@ __global__ __launch_bounds__(64) void k4_diag0(const UnitDesc *__restrict__ unit
 constexpr uint32_t ENT_LANES = 8;
 constexpr uint32_t ENT_LONG = 1u << 16;     // columns: longer candidates (the main diagonal of a self unit: the whole scaffold) ...
 constexpr uint32_t ENT_BIGCAP = 4096;       // ... are counted by the whole grid (k4_entropy_big), up to this many per batch
+constexpr uint32_t ENT_STAGE = 64;   // HSPs a wavefront collects before it appends them (8 per step at most)
+__device__ __forceinline__ void entropy_flush(const mimeo_hsp *sh, const uint32_t *su, uint32_t &n, const ExtQueues &q, mimeo_hsp *__restrict__ out,
+                                              uint32_t *__restrict__ out_unit) {
+    __builtin_amdgcn_wave_barrier();
+    if (n) {
+        const uint32_t lane = threadIdx.x & 63u;
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&q.ctr->nhsp, (unsigned long long)n);
+        b = __shfl(b, 0);
+        if (lane < n) { out[b + lane] = sh[lane]; out_unit[b + lane] = su[lane]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    n = 0;
+}
 __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(const UnitDesc *__restrict__ units, ExtQueues q, int hspthresh,
                                                           int entropy, mimeo_hsp *__restrict__ out,
                                                           uint32_t *__restrict__ out_unit) {
+    __shared__ mimeo_hsp s_h[EXT_THREADS / 64][ENT_STAGE];
+    __shared__ uint32_t s_u[EXT_THREADS / 64][ENT_STAGE];
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t nstage = 0;
     const uint32_t sub = threadIdx.x & (ENT_LANES - 1u);
     const uint64_t ncand = min((uint64_t)q.ctr->ncand, q.cand_cap);
     const uint64_t ngroups = ((uint64_t)gridDim.x * EXT_THREADS) / ENT_LANES;
@@ -540,23 +621,24 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_entropy(const UnitDesc *__rest
         q16 = q16 > 65536 ? 65536 : (q16 < 0 ? 0 : q16);
         adj = (raw * q16) >> 16;
     }
-    // one atomic per wavefront and step (1.5 M same-address atomics per C4 row would serialise at ~13 ns each)
+    // The HSPs wait in LDS until the wavefront has 64 of them: one atomic per wavefront and STEP was 2.5 * 10^6 same-address
+    // atomics for the 2.7 * 10^7 candidates of 32 C5 units — 13 ns each, the whole duration of this kernel
     const bool emit = live && !deferred && adj >= hspthresh && sub == 0;
     const uint64_t em = __ballot(emit);
     if (em) {
-        const uint32_t lane = threadIdx.x & 63u;
-        unsigned long long b = 0;
-        if (lane == (uint32_t)__builtin_ctzll(em)) b = atomicAdd(&q.ctr->nhsp, (unsigned long long)__popcll(em));
-        b = __shfl(b, __builtin_ctzll(em));
+        const uint32_t add = (uint32_t)__popcll(em);
+        if (nstage + add > ENT_STAGE) entropy_flush(s_h[wv], s_u[wv], nstage, q, out, out_unit);
         if (emit) {
-            const unsigned long long i = b + __popcll(em & ((1ull << lane) - 1ull));
+            const uint32_t at = nstage + (uint32_t)__popcll(em & ((1ull << (threadIdx.x & 63u)) - 1ull));
             mimeo_hsp h;
             h.tstart = c.tstart; h.qstart = c.qstart; h.length = c.len; h.flags = 0; h.score = adj; h.raw_score = raw;
-            out[i] = h;   // at most one HSP per candidate: the buffers hold cand_cap records
-            out_unit[i] = c.unit;
+            s_h[wv][at] = h;   // at most one HSP per candidate: the buffers hold cand_cap records
+            s_u[wv][at] = c.unit;
         }
+        nstage += add;
     }
     }
+    entropy_flush(s_h[wv], s_u[wv], nstage, q, out, out_unit);
 }
 
 // the long candidates: every workgroup counts a slice (matched columns per base, and the raw score again in 64 bits
