@@ -447,27 +447,47 @@ __global__ __launch_bounds__(EXT_THREADS) void k4_resolve_segments(const UnitDes
     if ((threadIdx.x & 63) == 0) w0 = atomicAdd(&q.ctr->seg_next, (unsigned long long)CLAIM);
     w0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w0);
     if (w0 >= nlist) break;
+    // the heads of the 16 segments, one per lane: four dependent loads for all of them instead of four for each
+    uint64_t l_beg = 0, l_end = 0, l_k0 = 0;
+    uint32_t l_het = 0;
+    if ((threadIdx.x & 63u) < CLAIM && w0 + (threadIdx.x & 63u) < nlist) {
+        const uint64_t sid = list[w0 + (threadIdx.x & 63u)];
+        l_beg = seg_start[sid];
+        l_end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
+        l_k0 = key[l_beg];
+        l_het = prev[l_beg];
+    }
     for (uint64_t wid = w0; wid < min(nlist, (uint64_t)w0 + CLAIM); wid++) {
-    const uint64_t sid = list[wid];
-    uint64_t beg = seg_start[sid], end = sid + 1 < nseg ? seg_start[sid + 1] : nfollow;
-    uint64_t k0 = key[beg];
+    const int src = (int)(wid - w0);
+    uint64_t beg = __shfl(l_beg, src), end = __shfl(l_end, src);
+    uint64_t k0 = __shfl(l_k0, src);
     const uint32_t unit = key_unit(q, k0);
     const StrandView T = units[unit].T, Q = units[unit].Q;
     const int32_t d = key_diag(q, k0, Q.len);
     // head: seed end = prev[beg]; only its right extent matters (it was emitted by the heavy kernel or the walks)
-    int32_t het = (int32_t)prev[beg];
+    int32_t het = (int32_t)__shfl(l_het, src);
     WalkResult R = wave_walk_fast(T, Q, het, d, +1, min(T.len - (uint32_t)het, Q.len - (uint32_t)(het - d)), xdrop);
     uint32_t reach = (uint32_t)het + R.bsteps;
     uint64_t i = beg;
     while (i < end) {
         // first record at or after i that reaches beyond `reach` (records are sorted by seed end; a RUN_END record stands for
         // every position behind the record before it up to its own)
-        uint64_t lo = i, hi = end;
-        while (lo < hi) {
-            uint64_t mid = (lo + hi) >> 1;
-            if (key_end(q, key[mid]) > reach) hi = mid; else lo = mid + 1;
+        // (the next 64 records in one load, lane by lane — most segments end there; a binary search, one memory round trip per
+        // step, only behind them)
+        uint64_t nxt;
+        {
+            const uint64_t x = i + (threadIdx.x & 63u);
+            const uint64_t m = __ballot(x < end && key_end(q, key[x]) > reach);
+            if (m) nxt = i + (uint64_t)__builtin_ctzll(m);
+            else {
+                uint64_t lo = min(end, i + 64u), hi = end;
+                while (lo < hi) {
+                    uint64_t mid = (lo + hi) >> 1;
+                    if (key_end(q, key[mid]) > reach) hi = mid; else lo = mid + 1;
+                }
+                nxt = lo;
+            }
         }
-        uint64_t nxt = lo;
         if (nxt >= end) break;
         uint32_t et = key_end(q, key[nxt]);
         if (prev[nxt] == RUN_END) et = max(key_end(q, key[nxt - 1]) + 1u, reach + 1u);   // the first member of the run beyond the reach
