@@ -116,3 +116,21 @@ def test_chain_default_dispatch_on_a_large_group(eng, monkeypatch):
         h = _make(kind, 40_000, rng)
         assert h.size > 33_000, (kind, h.size)
         assert _check(eng, O, h, (kind, 'large')) > 0
+
+
+def test_wave_and_two_level_kernels_agree_on_a_million_hsps(eng, monkeypatch):
+    """beyond what the O(n^2) oracle can check: 1.2 * 10^6 HSPs (rectangles of a microsatellite-rich pair mixed with random
+    boxes and collinear runs) through the wave kernel and through the two-level kernel — two algorithms, one set of flags"""
+    for k in ('MIMEO_K5_BIG_MIN', 'MIMEO_K5_BIG', 'MIMEO_K5_NO_BIG'):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(99)
+    parts = [_make('rectangles', 600_000, rng), _make('random', 400_000, rng), _make('collinear', 200_000, rng)]
+    parts[1]['tstart'] += 1000; parts[2]['qstart'] += 500
+    h = _unique(np.concatenate(parts))
+    assert h.size > 1_000_000
+    wave = eng.chain_hsps(h)
+    monkeypatch.setenv('MIMEO_K5_BIG', 'old')
+    old = eng.chain_hsps(h)
+    monkeypatch.delenv('MIMEO_K5_BIG')
+    assert wave.tobytes() == old.tobytes()
+    assert int((wave['flags'] & 1).sum()) > 100
