@@ -233,6 +233,7 @@ struct ExtBatch {
     std::vector<uint64_t> walk_cap_u_;   // walk-queue capacity per unit and shard
     uint64_t walk_entries_ = 0;          // ... all regions together
     uint32_t nactive_ = 0;               // units of the batch that launch the heavy kernels
+    const unsigned int *plan_ctr_ = nullptr;   // the split pass plan's counters on the device (statistics)
     uint64_t cap_f_ = 0, cap_m_ = 0, cap_l_ = 0, cap_c_ = 0;
     double expect_hits_ = 0, shrink_ = 1.0;
     uint32_t ebits_ = 0, dbits_ = 0, key_bits_ = 0;

@@ -283,6 +283,47 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
         }
         unsigned long long hits_acc = 0;   // pairs this wavefront enumerates in this tile (wave-uniform): the tile's exact hit count
+        // 64 pairs, one per lane: the target entry's frame and position, the query entry qi of the current segment (first entry qs)
+        auto pair_round = [&](const bool valid, const uint4 ta, const uint4 tb, const uint4 tc, const uint32_t tpf, const uint32_t qi, const uint32_t qs) {
+            const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
+            const uint32_t qflag = sQN[qi];
+            bool need = false;
+            uint32_t qp = 0;
+            bool live = valid;   // still to be looked at by the pre-filter
+            if (HEAVY && !(A.dbg & 16u)) {
+                // interior members of runs of consecutive seed hits leave no record: out, before the filter (a microsatellite
+                // tile is nearly all of them: whole rounds skip the filter)
+                bool inner = false;
+                if (valid && ((tpf >> 31) | qflag) == 0 && U.Tv.svt == nullptr && run_interior(ta, tb, tc, qa, qb, qc, A.transitions)) {
+                    const uint32_t tp = tpf & POS_MASK;
+                    inner = tp >= 2u && tp + 1u + SEED_LEN <= U.Tv.len;   // (the query's ends: bit 1 of its flag)
+                }
+                live = valid && !inner;
+            }
+            if (__ballot(live)) {
+                if (live) {
+                    if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
+                    else need = ((tpf >> 31) | (qflag & 1u)) != 0 ||
+                                pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
+                    if (A.dbg & 2u) need = false;
+                }
+            }
+            if (U.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
+                if (valid) {
+                    qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
+                    if ((tpf & POS_MASK) == qp) need = false;
+                }
+            } else if (need) {
+                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
+            }
+            const uint64_t m = __ballot(need);
+            if (m) {
+                const uint32_t add = (uint32_t)__popcll(m);
+                if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
+                if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
+                n_walk += add;
+            }
+        };
         const uint32_t q_begin = HEAVY ? part_qa : 0u, q_end = HEAVY ? min(part_qb, nQ) : nQ;
         for (uint32_t qs = q_begin; qs < q_end; qs += QSEG) {
             const uint32_t qn = min(QSEG, q_end - qs), qe = qs + qn;
@@ -299,7 +340,9 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     sQF[i] = s0[i];
                     sQF[QSEG + i] = s1[i];
                     sQF[2 * QSEG + i] = s2[i];
-                    sQN[i] = (uint8_t)(U.Q.pos[q0 + qs + i] >> 31);
+                    // bit 0: N in the frame; bit 1: too close to an end of the scaffold for the run test's three seed windows
+                    const uint32_t pq = U.Q.pos[q0 + qs + i], pp = pq & POS_MASK;
+                    sQN[i] = (uint8_t)((pq >> 31) | ((pp >= 2u && pp + 1u + SEED_LEN <= U.Qv.len) ? 0u : 2u));
                 }
             }
             __syncthreads();
@@ -374,44 +417,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                         // the target frame lives in its owner lane's registers, the query frame in LDS
                         const uint4 ta = bperm4(owner, f0), tb = bperm4(owner, f1), tc = bperm4(owner, f2);
                         const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
-                        const uint4 qa = sQF[qi], qb = sQF[QSEG + qi], qc = sQF[2 * QSEG + qi];
-                        bool need = false;
-                        uint32_t qp = 0;
-                        bool live = valid;   // still to be looked at by the pre-filter
-                        if (HEAVY && !(A.dbg & 16u)) {
-                            // interior members of runs of consecutive seed hits leave no record: out, before the filter (a microsatellite
-                            // tile is nearly all of them: whole rounds skip the filter)
-                            bool inner = false;
-                            if (valid && ((tpf >> 31) | sQN[qi]) == 0 && U.Tv.svt == nullptr && run_interior(ta, tb, tc, qa, qb, qc, A.transitions)) {
-                                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
-                                const uint32_t tp = tpf & POS_MASK;
-                                inner = tp >= 2u && qp >= 2u && tp + 1u + SEED_LEN <= U.Tv.len && qp + 1u + SEED_LEN <= U.Qv.len;
-                            }
-                            live = valid && !inner;
-                        }
-                        if (__ballot(live)) {
-                            if (live) {
-                                if (A.dbg & 1u) need = (ta.x ^ qa.x ^ tb.y ^ qb.y ^ tc.z ^ qc.z) == 0x12345u;
-                                else need = ((tpf >> 31) | sQN[qi]) != 0 ||
-                                            pair_needs_walk(ta, tb, tc, qa, qb, qc, A.xdrop, A.hspthresh, A.transitions);
-                                if (A.dbg & 2u) need = false;
-                            }
-                        }
-                        if (U.same) {  // the main diagonal of a self unit belongs to k4_diag0 (one unit in 2 S: the slow way will do)
-                            if (valid) {
-                                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
-                                if ((tpf & POS_MASK) == qp) need = false;
-                            }
-                        } else if (need) {
-                            qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
-                        }
-                        const uint64_t m = __ballot(need);
-                        if (m) {
-                            const uint32_t add = (uint32_t)__popcll(m);
-                            if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
-                            if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
-                            n_walk += add;
-                        }
+                        pair_round(valid, ta, tb, tc, tpf, qi, qs);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

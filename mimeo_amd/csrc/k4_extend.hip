@@ -1046,6 +1046,7 @@ int ExtBatch::enqueue_heavy() {
                 plan.tile = (uint2 *)(plan.split + slots);              // slots * 8
                 plan.base = (uint32_t *)(plan.tile + slots);            // (slots + 1) * 4
                 plan.ctr = (unsigned int *)(plan.base + slots + 4);     // 3 counters
+                plan_ctr_ = plan.ctr;
                 q.nwalk_u = (unsigned long long *)nwalk_u.p;
                 q.nheavy_u = q.nwalk_u + (size_t)nactive * 8;
                 HIP_TRY(hipMemcpyAsync(funits.p, h_funits_.data(), (size_t)nactive * sizeof(FusedUnit), hipMemcpyHostToDevice, st));
@@ -1188,6 +1189,11 @@ int ExtBatch::finish(uint64_t *nhsp_out, ExtStats *stats) {
         if (k34_dbg_ & 8)
             fprintf(stderr, "[k34] passed on because: left stop unproven %llu, right %llu, bound %llu, alarm %llu; ONLY alarm %llu, only left %llu, only right %llu, only bound %llu\n",
                     c.dbg[0], c.dbg[1], c.dbg[2], c.dbg[3], c.dbg[4], c.dbg[5], c.dbg[6], c.dbg[7]);
+        if (k4_stats_ && plan_ctr_ && nactive_) {
+            unsigned int pc[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpy(pc, plan_ctr_, 12, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[k34] split pass: %u tiles listed of %u, %u parts of ~131072 hits\n", pc[1], nactive_ * (unsigned)NTILE, pc[2]);
+        }
         if (k4_stats_)
             fprintf(stderr, "[k4] units %u walk queue %llu walked %llu generic %llu long %llu followers %llu candidates %llu hsps %llu%s\n", nunits,
                     c.nwalk_total, c.nwalked, (unsigned long long)nm, c.nlong, (unsigned long long)nf, c.ncand, c.nhsp, over ? "  (queue overflow: batch repeated)" : "");
