@@ -151,6 +151,11 @@ __device__ __forceinline__ bool run_interior(const uint4 t0, const uint4 t1, con
     return all;
 }
 
+constexpr uint32_t DENSE_MIN = 48;   // split pass: a probe's range of this many entries or more is enumerated densely
+__device__ __forceinline__ uint4 readlane4(const uint4 v, int lane) {   // lane: wave-uniform
+    return make_uint4((uint32_t)__builtin_amdgcn_readlane((int)v.x, lane), (uint32_t)__builtin_amdgcn_readlane((int)v.y, lane),
+                      (uint32_t)__builtin_amdgcn_readlane((int)v.z, lane), (uint32_t)__builtin_amdgcn_readlane((int)v.w, lane));
+}
 __device__ __forceinline__ uint4 bperm4(uint32_t src_lane, const uint4 v) {
     const int a = (int)(src_lane << 2);
     return make_uint4((uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.x), (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)v.y),
@@ -360,13 +365,14 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 }
                 const bool tvalid = lane < ne;
                 // my entry's in-tile key from its own frame: hi plane, seed window = frame bits 109 .. 127 (hi3 = f2.y)
-                uint32_t w = 0, c = 0, nmask = 0;
+                uint32_t w = 0, c = 0, nmask = 0, dmask = 0;   // dmask (split pass): probes whose range is enumerated densely, below
                 if (tvalid) {
                     w = pext12(f2.y >> 13);
                     const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
                     for (int j = 0; j < nn; j++) {
                         const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
                         const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                        if (HEAVY && b - a >= DENSE_MIN) { dmask |= 1u << j; continue; }
                         c += b - a;
                         nmask |= (b != a ? 1u : 0u) << j;
                     }
@@ -420,6 +426,28 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                         pair_round(valid, ta, tb, tc, tpf, qi, qs);
                     }
                     __builtin_amdgcn_wave_barrier();
+                }
+                if (HEAVY) {
+                    // Long ranges — a microsatellite's key holds hundreds of the segment's entries, and the split pass is made of
+                    // such tiles — are not written out as descriptors: for one target entry at a time (its frame in scalar
+                    // registers) the lanes take 64 consecutive query entries of the range, whose frames are conflict-free LDS
+                    // reads.  No descriptor is written or read and no lane shuffle fetches a frame: the enumeration was 57 % of
+                    // the split pass.
+                    for (uint64_t lm = __ballot(dmask != 0u); lm; lm &= lm - 1ull) {
+                        const int o = __builtin_ctzll(lm);
+                        const uint4 ta = readlane4(f0, o), tb = readlane4(f1, o), tc = readlane4(f2, o);
+                        const uint32_t tpf = (uint32_t)__builtin_amdgcn_readlane((int)mypos, o), wo = (uint32_t)__builtin_amdgcn_readlane((int)w, o);
+                        for (uint32_t dm = (uint32_t)__builtin_amdgcn_readlane((int)dmask, o); dm; dm &= dm - 1u) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(dm), w2 = j ? (wo ^ (1u << (j - 1u))) : wo;
+                            const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                            hits_acc += b - a;
+                            if (A.dbg & 4u) continue;
+                            for (uint32_t i = a; i < b; i += 64u) {
+                                const bool valid = i + lane < b;
+                                pair_round(valid, ta, tb, tc, tpf, valid ? i + lane : a, qs);
+                            }
+                        }
+                    }
                 }
             }
         }
