@@ -212,7 +212,12 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         const uint32_t shard = (HEAVY ? blockIdx.x + part_no : blockIdx.x) & 7u;
         if (lane == 0) b = atomicAdd(&A.q.nwalk_u[(size_t)ai * 8 + shard], (unsigned long long)n);
         b = __shfl(b, 0);
-        if (lane < n && b + lane < U.walk_cap) A.q.walkq[U.walk_base + (size_t)shard * U.walk_cap + b + lane] = s_walk[lane];
+        // (a staged pair names its query ENTRY: the positions of all 64 are fetched here, one gather per flush instead of one per round)
+        if (lane < n && b + lane < U.walk_cap) {
+            uint2 e = s_walk[lane];
+            e.y = U.Q.pos[e.y] & POS_MASK;
+            A.q.walkq[U.walk_base + (size_t)shard * U.walk_cap + b + lane] = e;
+        }
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -318,14 +323,12 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
                     if ((tpf & POS_MASK) == qp) need = false;
                 }
-            } else if (need) {
-                qp = U.Q.pos[q0 + qs + qi] & POS_MASK;
             }
             const uint64_t m = __ballot(need);
             if (m) {
                 const uint32_t add = (uint32_t)__popcll(m);
                 if (n_walk + add > 64u) { flush_walk(n_walk); n_walk = 0; }
-                if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, qp);
+                if (need) s_walk[n_walk + __popcll(m & lt_mask)] = make_uint2(tpf & POS_MASK, q0 + qs + qi);   // the query entry: flush_walk looks its position up
                 n_walk += add;
             }
         };
