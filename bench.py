@@ -85,13 +85,12 @@ def row_of(step_no, world, rank, nscaf):
 
 def a11_filter(alns, min_len, min_idt):
     """The awk filters of wrappers.py:1043-1052 on engine records: length1 = end1 - start1 + 1 >= minLen
-    and the PRINTED one-decimal identity >= minIdt (formats.identity_pct, element-wise)."""
+    and the PRINTED one-decimal identity >= minIdt (formats.printed_tenths: the digits '%.1f' prints, element-wise)."""
     if not alns.size:
         return alns
+    from mimeo_amd import formats
     a = alns[alns['tend'].astype(np.int64) - alns['tstart'] >= min_len]
-    d = a['id_d'].astype(np.float64)
-    pct = np.char.mod('%.1f', np.where(d > 0, 100.0 * a['id_n'] / np.maximum(d, 1), 0.0)).astype(np.float64)
-    return a[pct >= min_idt]
+    return a[formats.printed_tenths(a['id_n'], a['id_d']) / 10.0 >= min_idt]
 
 
 def cpu_oracle_times(pair_jobs, threads=1):

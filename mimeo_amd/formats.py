@@ -69,6 +69,23 @@ def identity_pct(n, d):
     return '%.1f' % (100.0 * n / d) if d else '0.0'
 
 
+def printed_tenths(id_n, id_d):
+    """The digits of `'%.1f' % (100 n / d)` as an integer (80.0 -> 800), element-wise: lastz prints identity `%.1f%%`, the
+    reference strips the % (wrappers.py:1040) and awk compares the PRINTED one-decimal value with minIdt (wrappers.py:1052):
+    format first, compare the formatted number.  '%.1f' rounds the double's exact value half-even: floor(10 v + 1/2) away
+    from a tie, Python's own formatting within 1e-6 of one (10 v carries a rounding error of its own there)."""
+    idn, idd = np.asarray(id_n, dtype=np.float64), np.asarray(id_d, dtype=np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        val = np.where(idd > 0, 100.0 * idn / idd, 0.0)
+    x10 = val * 10.0
+    fl = np.floor(x10)
+    frac = x10 - fl
+    tenths = (fl + (frac > 0.5)).astype(np.int64)
+    for i in np.flatnonzero(np.abs(frac - 0.5) < 1e-6).tolist():
+        tenths[i] = int(('%.1f' % val[i]).replace('.', ''))
+    return tenths
+
+
 def tab_blocks(alns, tnames, qnames, min_len, min_idt):
     """Every pair's block of the 10-column TAB at once (wrappers.py:1043-1056, per pair:
     awk '0+$5 >= minLen' | awk '0+$13 >= minIdt {print $1,$2,$3,$4,$6,$7,$8,$9,$11,$13}' | sort -k 1,1 -k 3n,4n).
@@ -80,19 +97,7 @@ def tab_blocks(alns, tnames, qnames, min_len, min_idt):
     if alns.size == 0:
         return {}, np.zeros((0, 4), dtype=np.int64)
     ts, te = alns['tstart'].astype(np.int64), alns['tend'].astype(np.int64)
-    idn, idd = alns['id_n'].astype(np.float64), alns['id_d'].astype(np.float64)
-    with np.errstate(divide='ignore', invalid='ignore'):
-        val = np.where(idd > 0, 100.0 * idn / idd, 0.0)
-    # lastz prints identity `%.1f%%`; the reference strips the % (wrappers.py:1040) and awk compares the printed
-    # one-decimal value with minIdt (wrappers.py:1052): format first, compare the formatted number.  tenths = the digits
-    # '%.1f' prints: round-half-even of the double's exact value — floor(10 v + 1/2) away from a tie, Python's own
-    # formatting within 1e-6 of one (10 v carries a rounding error of its own there)
-    x10 = val * 10.0
-    fl = np.floor(x10)
-    frac = x10 - fl
-    tenths = (fl + (frac > 0.5)).astype(np.int64)
-    for i in np.flatnonzero(np.abs(frac - 0.5) < 1e-6).tolist():
-        tenths[i] = int(('%.1f' % val[i]).replace('.', ''))
+    tenths = printed_tenths(alns['id_n'], alns['id_d'])
     keep = (te - ts >= min_len) & (tenths >= int(min_idt) * 10 if float(min_idt) == int(min_idt) else tenths / 10.0 >= min_idt)   # length1 = end1 - start1 + 1 = te - ts
     idx = np.flatnonzero(keep)
     if idx.size == 0:
