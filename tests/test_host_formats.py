@@ -95,3 +95,26 @@ def test_read_fasta_and_chromlens(tmp_path):
 def test_identity_rounding_is_printf():
     assert formats.identity_pct(1599, 2000) == '%.1f' % (100.0 * 1599 / 2000)
     assert formats.identity_pct(1, 1) == '100.0'
+
+
+def test_printed_tenths_is_what_printf_prints():
+    """The vectorised digits of the printed identity (wrappers.py:1040, :1052: awk compares the PRINTED one-decimal value with
+    minIdt) against Python's own '%.1f' on 3 * 10^5 (n, d) pairs: random ones, every n for a few denominators that make exact
+    x.x5 ties (2000, 400, 8000), d = 0, and the A11 filter of bench.py built on it against the formatted strings."""
+    rng = np.random.default_rng(5)
+    d = rng.integers(1, 200_000, 250_000)
+    n = (d * rng.uniform(0.5, 1.0, d.size)).astype(np.int64)
+    for den in (2000, 400, 8000, 3, 7):
+        k = np.arange(0, den + 1)
+        d, n = np.concatenate([d, np.full(k.size, den)]), np.concatenate([n, k])
+    d, n = np.concatenate([d, np.zeros(5, np.int64)]), np.concatenate([n, np.arange(5)])
+    got = formats.printed_tenths(n, d)
+    exp = np.array([int(('%.1f' % (100.0 * a / b)).replace('.', '')) if b else 0 for a, b in zip(n.tolist(), d.tolist())])
+    assert np.array_equal(got, exp)
+    import bench
+    a = np.zeros(n.size, dtype=_ffi.ALIGNMENT)
+    a['tend'] = 500
+    a['id_n'], a['id_d'] = n, d
+    for min_idt in (80, 95, 98, 87.5):
+        keep = np.array([float('%.1f' % (100.0 * x / y)) if y else 0.0 for x, y in zip(n.tolist(), d.tolist())]) >= min_idt
+        assert np.array_equal(bench.a11_filter(a, 100, min_idt)['id_n'], a['id_n'][keep])
