@@ -59,3 +59,36 @@ def test_collapse_known_answers():
         got = P.coverage_collapse([tuple(x) for x in case['intervals']], case['chromlens'],
                                   case['min_cov'], case['min_len'])
         assert [list(x) for x in got] == case['expect'], case['name']
+
+
+def test_chain_stage_of_the_c_oracle_against_the_rule_spelled_out():
+    """`orc_chain_hsps` (oracle/mimeo_oracle.c: chain_hsps — what tests/test_gpu_chain.py holds the three GPU chain kernels to)
+    against DESIGN.md §2 rule 5 written out in plain Python: HSPs in (tstart, qstart, length) order, best[j] = score[j] +
+    max(0, best[i]) over the i that end at or before j's start in both sequences, ties to the earliest predecessor and the
+    earliest end.  PARITY UNPINNED like every LASTZ-shaped stage: the reference holds no chain fixture."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    for n, span, equal in ((1, 100, False), (2, 100, False), (60, 3000, False), (400, 20000, False), (300, 1500, True)):
+        h = np.zeros(n, dtype=O.HSP)
+        h['tstart'], h['qstart'] = rng.integers(0, span, n), rng.integers(0, span, n)
+        h['length'] = 40 if equal else rng.integers(20, 300, n)
+        h['score'] = 3000 if equal else h['length'].astype(np.int64) * 90 - rng.integers(0, 500, n)
+        key = np.stack([h['tstart'], h['qstart'], h['length']], 1)
+        h = h[np.unique(key, axis=0, return_index=True)[1]]
+        got = O.chain_hsps(h[rng.permutation(h.size)])
+        s = h[np.lexsort((h['length'], h['qstart'], h['tstart']))]
+        best, pred = [0] * s.size, [-1] * s.size
+        for j in range(s.size):
+            b, p = 0, -1
+            for i in range(j):
+                if s['tstart'][i] + s['length'][i] <= s['tstart'][j] and s['qstart'][i] + s['length'][i] <= s['qstart'][j] and best[i] > b:
+                    b, p = best[i], i
+            best[j], pred[j] = b + int(s['score'][j]), p
+        flags = np.zeros(s.size, dtype=np.uint32)
+        k = int(np.argmax(best))   # first maximum
+        while k >= 0:
+            flags[k] = 1
+            k = pred[k]
+        assert np.array_equal(got['tstart'], s['tstart']) and np.array_equal(got['length'], s['length'])
+        assert np.array_equal(got['flags'] & 1, flags), (n, span, equal)
