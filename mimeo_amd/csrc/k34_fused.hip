@@ -281,6 +281,18 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             ro[i] = 0;
             if (k <= TILE_WORDS) ro[i] = (HEAVY ? qoff[k] : (k < TILE_WORDS ? (reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[k] : q0 + nQ)) - q0;
         }
+        // First pass, a tile of two segments (every C4 tile): the cut is put at key TILE_WORDS / 2 when both halves fit a segment.
+        // A key and its 13 probes differ in one bit, so in the segment of half h an entry whose key lies in h finds ALL its
+        // partners there but the one of bit 11, and an entry of the other half only that one: 13 probes per entry and tile
+        // instead of 26 (a chunk of one kind takes 12 probes or 1, wave-uniformly; the one mixed chunk of a tile all 13 —
+        // the clamped offsets make every probe right in any segment).  bit 5 (32) of the switch word = off; bit 6 (64) = the
+        // first pass as it was before both this and the level emission below.
+        bool aligned = false;
+        uint32_t mid = 0;
+        if (!HEAVY && nQ > QSEG && !(A.dbg & (32u | 64u))) {
+            mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)((reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[TILE_WORDS / 2] - q0));
+            aligned = mid <= QSEG && nQ - mid <= QSEG;   // (then 0 < mid < nQ: both segments hold entries)
+        }
         const uint4 *tF0 = U.T.fr + t0, *tF1 = tF0 + U.T.fr_stride, *tF2 = tF1 + U.T.fr_stride;
         const uint32_t nchunks = (nT + TCH - 1) / TCH;
         // chunks of this workgroup: every one (first pass), or those of my share of the tile (split pass)
@@ -333,8 +345,10 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
             }
         };
         const uint32_t q_begin = HEAVY ? part_qa : 0u, q_end = HEAVY ? min(part_qb, nQ) : nQ;
-        for (uint32_t qs = q_begin; qs < q_end; qs += QSEG) {
-            const uint32_t qn = min(QSEG, q_end - qs), qe = qs + qn;
+        for (uint32_t qs = q_begin, qe; qs < q_end; qs = qe) {
+            qe = aligned ? (qs ? q_end : mid) : min(qs + QSEG, q_end);
+            const uint32_t qn = qe - qs;
+            const uint32_t half = qs ? 1u : 0u;   // aligned tiles: the half of the key space this segment holds
             __syncthreads();  // every wavefront is through with the previous segment (and with the count prologue's use of the frame area)
             // the tile's offsets relative to this segment, clamped to it: key w's entries inside the segment are sQ[w] .. sQ[w + 1]
 #pragma unroll
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 const uint32_t mypos = npos;
                 {   // next chunk of this wavefront: the following one of this segment, or its first one for the next segment
                     uint32_t nx = ch + ch_step;
-                    if (nx >= nchunks) nx = (qs + QSEG < q_end) ? ch_first : 0xFFFFFFFFu;
+                    if (nx >= nchunks) nx = (qe < q_end) ? ch_first : 0xFFFFFFFFu;
                     if (nx != 0xFFFFFFFFu && nx != ch) {
                         const uint32_t e = nx * TCH + lane;
                         if (e < nT) { nf0 = tF0[e]; nf1 = tF1[e]; nf2 = tF2[e]; npos = U.T.pos[t0 + e]; }
@@ -369,9 +383,77 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 const bool tvalid = lane < ne;
                 // my entry's in-tile key from its own frame: hi plane, seed window = frame bits 109 .. 127 (hi3 = f2.y)
                 uint32_t w = 0, c = 0, nmask = 0, dmask = 0;   // dmask (split pass): probes whose range is enumerated densely, below
+                if (tvalid) w = pext12(f2.y >> 13);
+                const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
+                // the probes this chunk needs in this segment: all of them, or — aligned tiles, a chunk whose keys lie in one half of
+                // the key space (all but one chunk of a tile) — the key itself and its partners of bits 0 .. 10 when that is the
+                // segment's half, else the partner of bit 11 alone
+                if (!HEAVY && !(A.dbg & 64u)) {
+                    int jlo = 0, jhi = nn;
+                    if (aligned) {
+                        const uint64_t in_half = __ballot(tvalid && (w >> 11) == half), in_other = __ballot(tvalid && (w >> 11) != half);
+                        if (!in_other) jhi = min(nn, SEED_WEIGHT);
+                        else if (!in_half) jlo = SEED_WEIGHT;
+                    }
+                    jlo = __builtin_amdgcn_readfirstlane(jlo);   // (wave-uniform by construction: say so)
+                    jhi = __builtin_amdgcn_readfirstlane(jhi);
+                    // ---- first pass: descriptors written LEVEL BY LEVEL, probe-major.  For probe j, level k = the lanes whose range
+                    // holds more than k entries: their slots are ring position + v_mbcnt of the ballot, one LDS write each; a probe's
+                    // range holds 0.6 entries on average on a C4 tile, so a probe is two or three levels (the ballot of the next one is
+                    // empty).  No prefix sum over the lanes, no second visit of the offsets, no per-lane loop that runs as long as the
+                    // busiest lane's: the emission was 20 % of this kernel's time.  The ring holds 128 descriptors: a round of 64 pairs
+                    // runs as soon as 64 are waiting (MIMEO_K34_DEBUG bit 6 (64): the lane-major emission below, as in the split pass).
+                    constexpr uint32_t RING = 128;
+                    static_assert(RING <= DQ, "the ring lives in the wavefront's descriptor queue");
+                    const uint32_t l16 = lane << 16;
+                    uint32_t head = 0, tail = 0, pend = 0;   // ring positions (below RING) and descriptors waiting: wave-uniform
+                    uint32_t an = 0, cn = 0;
+                    auto fetch = [&](const int jj) {   // the range of probe jj in this segment, fetched a probe ahead of its use
+                        an = 0; cn = 0;
+                        if (tvalid && jj < jhi) {
+                            const uint32_t w2 = jj ? (w ^ (1u << (jj - 1))) : w;
+                            an = sQ[w2];
+                            cn = (uint32_t)sQ[w2 + 1] - an;
+                        }
+                    };
+                    auto round = [&](const uint32_t n) {   // the n <= 64 oldest descriptors of the ring
+                        __builtin_amdgcn_wave_barrier();
+                        const bool valid = lane < n;
+                        const uint32_t d = valid ? sD[(head + lane) & (RING - 1u)] : 0u;
+                        const uint32_t owner = d >> 16, qi = d & 0xFFFFu;
+                        if (!(A.dbg & 4u)) {
+                            const uint4 ta = bperm4(owner, f0), tb = bperm4(owner, f1), tc = bperm4(owner, f2);
+                            const uint32_t tpf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)mypos);
+                            pair_round(valid, ta, tb, tc, tpf, qi, qs);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        head = (head + 64u) & (RING - 1u);
+                        pend -= n;
+                    };
+                    fetch(jlo);
+#pragma unroll 1
+                    for (int j = jlo; j < jhi; j++) {
+                        const uint32_t ak = l16 | an, cnt = cn;
+                        fetch(j + 1);
+                        uint32_t k = 0;
+#pragma unroll 1
+                        for (uint64_t m = __ballot(cnt > 0u); m; m = __ballot(cnt > k)) {
+                            if (cnt > k) {
+                                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
+                                sD[slot & (RING - 1u)] = ak + k;
+                            }
+                            const uint32_t add = (uint32_t)__popcll(m);
+                            tail = (tail + add) & (RING - 1u);
+                            pend += add;
+                            hits_acc += add;
+                            k++;
+                            if (pend >= 64u) round(64u);   // (fewer than 64 waited before this level: the ring never overflows)
+                        }
+                    }
+                    if (pend) round(pend);   // the rest of this chunk's pairs
+                    continue;   // next chunk
+                }
                 if (tvalid) {
-                    w = pext12(f2.y >> 13);
-                    const int nn = A.transitions ? SEED_WEIGHT + 1 : 1;
                     for (int j = 0; j < nn; j++) {
                         const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
                         const uint32_t a = sQ[w2], b = sQ[w2 + 1];

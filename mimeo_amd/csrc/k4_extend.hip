@@ -893,6 +893,13 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
     // development / test switches: read once per batch, never per launch
     v1_ = getenv("MIMEO_HEAVY") && !strcmp(getenv("MIMEO_HEAVY"), "v1");
     k34_dbg_ = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
+    {   // the form of K34's first pass (k34_fused.hip; bits 5 and 6 of its switch word): "level" = two-segment tiles cut at the
+        // middle key + level emission, "cut" = level emission on tiles cut by entry count, "lane" = prefix sum + lane-major
+        // emission, the round-2/3 form.  MIMEO_K34_FORM picks one (tests, scripts/gpu_k34_ab.py).
+        const char *form = getenv("MIMEO_K34_FORM");
+        const uint32_t bits = !form ? K34_FORM_DEFAULT : !strcmp(form, "level") ? 0u : !strcmp(form, "cut") ? 32u : 64u;
+        k34_dbg_ = (k34_dbg_ & ~96u) | bits;
+    }
     k4_variant_ = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 0;
     qw_blocks_ = getenv("MIMEO_QW_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("MIMEO_QW_BLOCKS"))) : 256u;
     k4_stats_ = getenv("MIMEO_K4_STATS") != nullptr;
