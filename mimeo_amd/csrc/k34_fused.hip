@@ -285,11 +285,10 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         // A key and its 13 probes differ in one bit, so in the segment of half h an entry whose key lies in h finds ALL its
         // partners there but the one of bit 11, and an entry of the other half only that one: 13 probes per entry and tile
         // instead of 26 (a chunk of one kind takes 12 probes or 1, wave-uniformly; the one mixed chunk of a tile all 13 —
-        // the clamped offsets make every probe right in any segment).  bit 5 (32) of the switch word = off; bit 6 (64) = the
-        // first pass as it was before both this and the level emission below.
+        // the clamped offsets make every probe right in any segment).  Bit 5 (32) of the switch word: off (tiles cut by entry count).
         bool aligned = false;
         uint32_t mid = 0;
-        if (!HEAVY && nQ > QSEG && !(A.dbg & (32u | 64u))) {
+        if (!HEAVY && nQ > QSEG && !(A.dbg & 32u)) {
             mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)((reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[TILE_WORDS / 2] - q0));
             aligned = mid <= QSEG && nQ - mid <= QSEG;   // (then 0 < mid < nQ: both segments hold entries)
         }
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     // range holds 0.6 entries on average on a C4 tile, so a probe is two or three levels (the ballot of the next one is
                     // empty).  No prefix sum over the lanes, no second visit of the offsets, no per-lane loop that runs as long as the
                     // busiest lane's: the emission was 20 % of this kernel's time.  The ring holds 128 descriptors: a round of 64 pairs
-                    // runs as soon as 64 are waiting (MIMEO_K34_DEBUG bit 6 (64): the lane-major emission below, as in the split pass).
+                    // runs as soon as 64 are waiting (bit 6 (64) of the switch word: the lane-major emission below, as in the split pass).
                     constexpr uint32_t RING = 128;
                     static_assert(RING <= DQ, "the ring lives in the wavefront's descriptor queue");
                     const uint32_t l16 = lane << 16;
@@ -453,14 +452,22 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                     if (pend) round(pend);   // the rest of this chunk's pairs
                     continue;   // next chunk
                 }
-                if (tvalid) {
-                    for (int j = 0; j < nn; j++) {
-                        const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
-                        const uint32_t a = sQ[w2], b = sQ[w2 + 1];
-                        if (HEAVY && b - a >= DENSE_MIN) { dmask |= 1u << j; continue; }
-                        c += b - a;
-                        nmask |= (b != a ? 1u : 0u) << j;
-                    }
+                {
+                    auto probes = [&](const int jlo, const int jhi) {   // (constant bounds: unrolled, the offsets of four probes in flight)
+                        if (!tvalid) return;
+                        for (int j = jlo; j < jhi; j++) {
+                            const uint32_t w2 = j ? (w ^ (1u << (j - 1))) : w;
+                            const uint32_t a = sQ[w2], b = sQ[w2 + 1];
+                            if (HEAVY && b - a >= DENSE_MIN) { dmask |= 1u << j; continue; }
+                            c += b - a;
+                            nmask |= (b != a ? 1u : 0u) << j;
+                        }
+                    };
+                    const uint64_t in_half = (!HEAVY && aligned) ? __ballot(tvalid && (w >> 11) == half) : 1ull;
+                    const uint64_t in_other = (!HEAVY && aligned) ? __ballot(tvalid && (w >> 11) != half) : 1ull;
+                    if (in_half && in_other) probes(0, nn);
+                    else if (in_half) probes(0, min(nn, SEED_WEIGHT));
+                    else probes(SEED_WEIGHT, nn);
                 }
                 // inclusive prefix sum over the lanes: DPP (VALU latency), not six trips through the LDS crossbar
                 uint32_t inc = c;

@@ -893,11 +893,11 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
     // development / test switches: read once per batch, never per launch
     v1_ = getenv("MIMEO_HEAVY") && !strcmp(getenv("MIMEO_HEAVY"), "v1");
     k34_dbg_ = getenv("MIMEO_K34_DEBUG") ? (uint32_t)atoi(getenv("MIMEO_K34_DEBUG")) : 0u;
-    {   // the form of K34's first pass (k34_fused.hip; bits 5 and 6 of its switch word): "level" = two-segment tiles cut at the
-        // middle key + level emission, "cut" = level emission on tiles cut by entry count, "lane" = prefix sum + lane-major
-        // emission, the round-2/3 form.  MIMEO_K34_FORM picks one (tests, scripts/gpu_k34_ab.py).
+    {   // the form of K34's first pass (k34_fused.hip; bits 5 and 6 of its switch word): two-segment tiles cut at the middle key
+        // (0) or by entry count (32); descriptors written level by level (0) or lane-major behind a prefix sum (64).
+        // MIMEO_K34_FORM = level (0) | cut (32) | half (64) | lane (96: the round-2/3 form) picks one (tests, scripts/gpu_k34_ab.py).
         const char *form = getenv("MIMEO_K34_FORM");
-        const uint32_t bits = !form ? K34_FORM_DEFAULT : !strcmp(form, "level") ? 0u : !strcmp(form, "cut") ? 32u : 64u;
+        const uint32_t bits = !form ? K34_FORM_DEFAULT : !strcmp(form, "level") ? 0u : !strcmp(form, "cut") ? 32u : !strcmp(form, "half") ? 64u : 96u;
         k34_dbg_ = (k34_dbg_ & ~96u) | bits;
     }
     k4_variant_ = getenv("MIMEO_K4_VARIANT") ? atoi(getenv("MIMEO_K4_VARIANT")) : 0;

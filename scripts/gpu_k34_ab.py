@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: the first pass of K34 in its three forms, checked and timed in one process.
+"""GPU box: the first pass of K34 in its four forms, checked and timed in one process.
 
     python scripts/gpu_k34_ab.py  ->  gpurun_out/k34_ab.json
 
 Forms (MIMEO_K34_FORM, read per call): level = two-segment tiles cut at the middle key + level emission;
-cut = tiles cut by entry count + level emission; lane = the first pass as it was (13 probes per entry and segment, prefix
+cut = tiles cut by entry count + level emission; half = middle-key cut + lane-major emission; lane = the first pass as it was (13 probes per entry and segment, prefix
 sum, lane-major descriptor emission).  Checks: (a) 0.3 Mbp x 8 Mbp (two segments per tile) and three 0.2 Mbp scaffolds (one
 segment; a self unit) against the C oracle — HSPs and the seed-hit count, both strands; (b) units of 10 Mbp x 10 Mbp (C4)
 against MIMEO_HEAVY=v1, the round-1 decomposition (hit array + K4), byte for byte.  Timing: the K34 launches of a 16-pair
@@ -24,8 +24,8 @@ from mimeo_amd.synth import make_families, synth_genome   # noqa: E402
 from oracle import oracle as O                    # noqa: E402
 
 HCOLS = ['tstart', 'qstart', 'length', 'score', 'raw_score']
-FORMS = ('level', 'cut', 'lane')
-out = {'forms': {'level': 'middle-key cut + level emission', 'cut': 'entry-count cut + level emission', 'lane': 'first pass as before'},
+FORMS = ('level', 'cut', 'half', 'lane')
+out = {'forms': {'level': 'middle-key cut + level emission', 'cut': 'entry-count cut + level emission', 'half': 'middle-key cut + lane-major emission', 'lane': 'first pass as before'},
        'checks': [], 'timing': {}}
 ok = True
 

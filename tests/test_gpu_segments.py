@@ -95,15 +95,15 @@ def test_fullsize_units_fused_equals_round1_decomposition(eng, monkeypatch, seed
     """BASELINE-sized units: K34 (default) against MIMEO_HEAVY=v1 — the stand-alone seed scan K3 writing the hit
     array and round 1's K4 fast kernel reading it: another enumeration of the hits (no segments, no frames, no
     descriptors), another filter, the same exact walks — HSPs byte for byte, both strands, a cross unit and a self
-    unit, and the same number of seed hits.  And the three forms of K34's first pass (MIMEO_K34_FORM): two-segment tiles cut
+    unit, and the same number of seed hits.  And the four forms of K34's first pass (MIMEO_K34_FORM): two-segment tiles cut
     at the middle key with the level emission (a chunk of one half of the key space takes 12 probes or 1 instead of 13; a C2
-    tile is one segment and must not care), tiles cut by entry count with the level emission, prefix sum + lane-major
-    emission."""
+    tile is one segment and must not care), tiles cut by entry count with the level emission, and either cut with the prefix
+    sum + lane-major emission."""
     names, seqs = synth_genome(seed, 2 * L, 2, repeat_frac=0.05)
     g = eng.Genome(names, seqs)
     res = {}
     for tag, env in (('fused', {}), ('v1', {'MIMEO_HEAVY': 'v1'}), ('level', {'MIMEO_K34_FORM': 'level'}), ('cut', {'MIMEO_K34_FORM': 'cut'}),
-                     ('lane', {'MIMEO_K34_FORM': 'lane'})):
+                     ('half', {'MIMEO_K34_FORM': 'half'}), ('lane', {'MIMEO_K34_FORM': 'lane'})):
         _clear(monkeypatch)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -114,10 +114,10 @@ def test_fullsize_units_fused_equals_round1_decomposition(eng, monkeypatch, seed
                 hits.append(eng.stats()['seed_hits'])
         res[tag] = (out, hits)
     _clear(monkeypatch)
-    assert res['fused'][1] == res['v1'][1] == res['level'][1] == res['cut'][1] == res['lane'][1]
+    assert res['fused'][1] == res['v1'][1] == res['level'][1] == res['cut'][1] == res['half'][1] == res['lane'][1]
     assert res['fused'][1][0] > 13 * float(L) * L / 4 ** 12
-    for a, b, c, d, e in zip(res['fused'][0], res['v1'][0], res['level'][0], res['cut'][0], res['lane'][0]):
-        assert a.size == b.size > 100 and a.tobytes() == b.tobytes() == c.tobytes() == d.tobytes() == e.tobytes()
+    for a, *others in zip(*(res[k][0] for k in ('fused', 'v1', 'level', 'cut', 'half', 'lane'))):
+        assert a.size > 100 and all(a.tobytes() == o.tobytes() for o in others)
     g.close()
 
 
