@@ -8,10 +8,10 @@ namespace mimeo {
 
 constexpr uint32_t CARE19 = 0x7A997u;  // care positions of 1110100110010101111 (bit i = offset i)
 constexpr int EXT_THREADS = 256;
-// K34's first pass when MIMEO_K34_FORM is not set (k4_extend.hip reads it per batch): 96 = tiles cut by entry count, prefix sum +
-// lane-major descriptor emission, the form every committed measurement was made with; 0 = tiles cut at the middle key + level
-// emission (k34_fused.hip)
-constexpr uint32_t K34_FORM_DEFAULT = 96u;
+// K34's first pass when MIMEO_K34_FORM is not set (k4_extend.hip reads it per batch): 0 = tiles cut at the middle key + level
+// emission (k34_fused.hip; C4 row: K34 147.1 -> 136.1 ms per launch, every GPU test green under it); 96 = tiles cut by entry
+// count, prefix sum + lane-major descriptor emission: the form of rounds 2 and 3 up to profiles/r03_bench_c4_rows_line.json
+constexpr uint32_t K34_FORM_DEFAULT = 0u;
 constexpr int LONG_WINDOWS = 8;  // per-lane walks give up after 8*32 bases per direction
 
 // The extension stage works on a BATCH of units (one unit = one (target scaffold, query scaffold, strand)): the

@@ -10,10 +10,10 @@ OUT=$R/gpurun_out/${TAG}_pmc_k34_sq.json
 PARTS=$R/gpurun_out/pmc_parts
 rm -rf $PARTS && mkdir -p $PARTS
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD" \
-           "SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR" \
-           "SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE"; do
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD" \
+           "SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR"; do
   rm -rf $R/gpurun_out/pmc_tmp
   MIMEO_K34_DEBUG=${DBG:-0} rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_tmp -o run --output-format csv -- python3 $R/scripts/dev_unit.py 1e7 1000 > /dev/null 2>&1
   f=$(find $R/gpurun_out/pmc_tmp -name "*counter_collection.csv" | head -1)
