@@ -234,13 +234,17 @@ def pmc_traffic(workload):
 
 def valu_issue(avg_launch_ms):
     """What bounds K34: VALU issue.  insts_per_launch = SQ_INSTS_VALU of a first-pass launch on a C4 unit
-    (profiles/r03_pmc_k34_sq.json); cycles_per_inst_mix = its opcode mix from the ISA priced with the measured per-opcode issue
-    rates (scripts/k34_isa_mix.py -> profiles/r03_k34_isa_mix.json, profiles/r03_valu_rate.txt); frac_of_issue_peak = the
-    share of the 1024 SIMDs' issue time those instructions take at this run's launch duration."""
+    (profiles/r03b_pmc_k34_sq.json: the level form of the first pass, the shipped default); cycles_per_inst_mix = its opcode mix
+    from the ISA priced with the measured per-opcode issue rates (scripts/k34_isa_mix.py -> profiles/r03b_k34_isa_mix.json,
+    profiles/r03_valu_rate.txt); frac_of_issue_peak = the share of the 1024 SIMDs' issue time those instructions take at this
+    run's launch duration.  MIMEO_K34_FORM=lane (the form of rounds 2 and 3) is priced with the r03 files."""
+    tag = 'r03' if os.environ.get('MIMEO_K34_FORM') == 'lane' else 'r03b'
+    if os.environ.get('MIMEO_K34_FORM') in ('cut', 'half'):
+        return {'error': 'no counters on file for MIMEO_K34_FORM=' + os.environ['MIMEO_K34_FORM']}
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_k34_isa_mix.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', tag + '_k34_isa_mix.json')) as f:
             mix = json.load(f)
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_k34_sq.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', tag + '_pmc_k34_sq.json')) as f:
             pmc = json.load(f)['kernels']['k34_scan_extend (first pass)']
         insts, c = pmc['SQ_INSTS_VALU'], mix['cycles_per_inst_mix']
         return {'insts_per_launch': insts, 'cycles_per_inst_mix': c,
@@ -248,8 +252,8 @@ def valu_issue(avg_launch_ms):
                 'full_rate_share_of_valu': mix['dynamic_c4_unit']['full_rate_share_of_valu'],
                 'issue_cycles_at_2.4GHz': {k: mix['issue_cycles_at_2.4GHz'][k] for k in ('full_rate_class', 'half_rate_class')},
                 'lanes_active_per_valu_inst': mix['dynamic_c4_unit'].get('lanes_active_per_valu_inst'),
-                'source': 'profiles/r03_pmc_k34_sq.json (SQ_INSTS_VALU per first-pass launch, C4 unit), profiles/r03_k34_isa_mix.json (ISA opcode mix), '
-                          'profiles/r03_valu_rate.txt (cycles per opcode, MI355X)'}
+                'source': 'profiles/%s_pmc_k34_sq.json (SQ_INSTS_VALU per first-pass launch, C4 unit), profiles/%s_k34_isa_mix.json (ISA opcode mix), '
+                          'profiles/r03_valu_rate.txt (cycles per opcode, MI355X)' % (tag, tag)}
     except Exception as e:
         return {'error': repr(e)}
 

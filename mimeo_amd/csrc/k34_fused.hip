@@ -31,6 +31,14 @@
 
 namespace mimeo {
 
+// the form of the first pass = bits 5 and 6 of the switch word (do_tile).  scripts/k34_isa_mix.py compiles ONE form alone
+// (-DK34_ONLY_FORM=0) to read its ISA: the blocks of the form that does not run would dilute the opcode mix it prices.
+#ifdef K34_ONLY_FORM
+#define K34_FORM(dbg) ((uint32_t)(K34_ONLY_FORM))
+#else
+#define K34_FORM(dbg) ((dbg) & 96u)
+#endif
+
 constexpr uint32_t TCH = 64;      // target entries per wavefront and chunk: one per lane
 constexpr uint32_t DQ = 192;      // pair descriptors per wavefront and round
 constexpr uint32_t CARE10 = 0x1A997u;  // offsets 0 1 2 4 7 8 11 13 15 16 of CARE19
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
         // the clamped offsets make every probe right in any segment).  Bit 5 (32) of the switch word: off (tiles cut by entry count).
         bool aligned = false;
         uint32_t mid = 0;
-        if (!HEAVY && nQ > QSEG && !(A.dbg & 32u)) {
+        if (!HEAVY && nQ > QSEG && !(K34_FORM(A.dbg) & 32u)) {
             mid = (uint32_t)__builtin_amdgcn_readfirstlane((int)((reinterpret_cast<const uint32_t *>(sQF) + TILE_WORDS + 4)[TILE_WORDS / 2] - q0));
             aligned = mid <= QSEG && nQ - mid <= QSEG;   // (then 0 < mid < nQ: both segments hold entries)
         }
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(THREADS, 4) void k34_scan_extend(FusedArgs A) {
                 // the probes this chunk needs in this segment: all of them, or — aligned tiles, a chunk whose keys lie in one half of
                 // the key space (all but one chunk of a tile) — the key itself and its partners of bits 0 .. 10 when that is the
                 // segment's half, else the partner of bit 11 alone
-                if (!HEAVY && !(A.dbg & 64u)) {
+                if (!HEAVY && !(K34_FORM(A.dbg) & 64u)) {
                     int jlo = 0, jhi = nn;
                     if (aligned) {
                         const uint64_t in_half = __ballot(tvalid && (w >> 11) == half), in_other = __ballot(tvalid && (w >> 11) != half);

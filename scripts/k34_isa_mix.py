@@ -2,7 +2,11 @@
 """Opcode mix of the seed-scan kernel K34 from its ISA, priced with the measured per-opcode issue rates: what the
 `roofline.valu` block of the bench line is computed from.
 
-    python scripts/k34_isa_mix.py            -> profiles/r03_k34_isa_mix.json   (needs hipcc; run in the build container)
+    python scripts/k34_isa_mix.py [tag]      -> profiles/<tag>_k34_isa_mix.json   (needs hipcc; run in the build container)
+
+tag r03b (default): the level form of the first pass, compiled alone (-DK34_ONLY_FORM=0: the shipped kernel also holds the
+lane-major form behind a switch, whose blocks never run), counters from profiles/r03b_pmc_k34_sq.json; tag r03: the lane-major
+form (-DK34_ONLY_FORM=96) with profiles/r03_pmc_k34_sq.json — the mix behind profiles/r03_bench_c4_rows_line.json.
 
 Inputs
   * the device assembly of mimeo_amd/csrc/k34_fused.hip (hipcc -S --cuda-device-only, the Makefile's flags), first-pass
@@ -69,9 +73,11 @@ def classify(op):
 
 
 def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03b'
+    form = '96' if tag == 'r03' else '0'
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, 'k34.s')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-w', '-S',
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-w', '-S', '-DK34_ONLY_FORM=' + form,
                                '--cuda-device-only', '-o', asm, os.path.join(ROOT, 'mimeo_amd', 'csrc', 'k34_fused.hip')],
                               stderr=subprocess.DEVNULL)
         src = open(asm).read().split('\n')
@@ -131,7 +137,7 @@ def main():
         return sum(b[k] for b in bs)
 
     c_full, c_half, n_full, n_half = rates()
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_k34_sq.json')))['kernels']['k34_scan_extend (first pass)']
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_k34_sq.json')))['kernels']['k34_scan_extend (first pass)']
     insts = pmc['SQ_INSTS_VALU']
     lane_util = pmc['SQ_THREAD_CYCLES_VALU'] / insts / 64.0 if pmc.get('SQ_THREAD_CYCLES_VALU') else None
     # dynamic weights on a C4 unit: 7.78e7 seed hits; a round holds 64 descriptors but the last of a (wavefront, chunk visit) is
@@ -143,16 +149,23 @@ def main():
     round_valu = {'valu_full': filt['valu_full'] + per_block[fetch]['valu_full'], 'valu_half': filt['valu_half'] + per_block[fetch]['valu_half']}
     round_all = {'valu_full': tot(rnd, 'valu_full'), 'valu_half': tot(rnd, 'valu_half')}
     visit_all = {'valu_full': tot(visit, 'valu_full'), 'valu_half': tot(visit, 'valu_half')}
-    # rounds: partial last rounds — about half a round per visit on top of the full ones
-    rounds = rounds_full + 0.5 * visits
-    # a visit executes its probe block once and the emission loop body ~3.4 times (non-empty probes per lane, worst lane of 64: ~9)
-    model = rounds * (round_valu['valu_full'] + round_valu['valu_half']) + visits * (visit_all['valu_full'] + visit_all['valu_half']) * 1.6
+    if form == '96':
+        # lane-major form.  rounds: partial last rounds — about half a round per visit on top of the full ones; a visit executes its
+        # probe block once and the emission loop body ~3.4 times (non-empty probes per lane, worst lane of 64: ~9)
+        rounds = rounds_full + 0.5 * visits
+        model = rounds * (round_valu['valu_full'] + round_valu['valu_half']) + visits * (visit_all['valu_full'] + visit_all['valu_half']) * 1.6
+    else:
+        # level form.  The visit's last, partial round is a copy of the round among the visit's own blocks; the level loop body
+        # (~9 VALU) runs ~36 times in a visit of the segment's own half of the key space (12 probes x ~3 levels) and ~3 times in
+        # a visit of the other half: ~19.5 x 9 / 370 = +0.47 of the visit's static count
+        rounds = rounds_full
+        model = rounds * (round_valu['valu_full'] + round_valu['valu_half']) + visits * (visit_all['valu_full'] + visit_all['valu_half']) * 1.47
     share_round = rounds * (round_valu['valu_full'] + round_valu['valu_half']) / insts
     full_share = (rounds * round_valu['valu_full'] + (insts - rounds * (round_valu['valu_full'] + round_valu['valu_half'])) *
                   visit_all['valu_full'] / max(1, visit_all['valu_full'] + visit_all['valu_half'])) / insts
     c_mix = full_share * c_full + (1 - full_share) * c_half
     out = {
-        'what': 'opcode mix of k34_scan_extend<512,1280,false> (first pass) from its gfx950 ISA, priced with profiles/r03_valu_rate.txt',
+        'what': 'opcode mix of k34_scan_extend<512,1280,false> (first pass, %s form compiled alone) from its gfx950 ISA, priced with profiles/r03_valu_rate.txt' % ('lane-major' if form == '96' else 'level'),
         'issue_cycles_at_2.4GHz': {'full_rate_class': round(c_full, 3), 'half_rate_class': round(c_half, 3), 'ubench_rows': [n_full, n_half],
                                    'full_rate_ops': sorted(FULL_RATE)},
         'static': {'pair_round_blocks': rnd, 'prefilter_block': filt, 'chunk_visit_blocks': visit,
@@ -165,7 +178,7 @@ def main():
                 'time are both wall-clock based, so the nominal 2.4 GHz cancels.  SQ_ACTIVE_INST_VALU counts one quad-cycle per VALU '
                 'instruction whatever its rate (profiles/r03_pmc_k34_sq.json: ratio 1.000), so it cannot tell the two classes apart.',
     }
-    path = os.path.join(ROOT, 'profiles', 'r03_k34_isa_mix.json')
+    path = os.path.join(ROOT, 'profiles', tag + '_k34_isa_mix.json')
     json.dump(out, open(path, 'w'), indent=1)
     print(json.dumps({k: out[k] for k in ('issue_cycles_at_2.4GHz', 'dynamic_c4_unit', 'cycles_per_inst_mix')}, indent=1))
     print('pair round: %d blocks, straight line %s; pre-filter block %s; chunk visit %d blocks %s' % (
