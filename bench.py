@@ -218,14 +218,14 @@ def reference_tools_check():
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the seed-scan kernel K34 from the committed rocprofv3 PMC passes
-    (profiles/r03_pmc_seed_scan.json, scripts/gpu_pmc_traffic.sh): FETCH_SIZE doubled (gfx950 tallies the 128-byte
+    (profiles/r03b_pmc_seed_scan.json — the final build —, scripts/gpu_pmc_traffic.sh): FETCH_SIZE doubled (gfx950 tallies the 128-byte
     requests of wide coalesced reads as 64 bytes: MI355X_MICROARCH.md, HBM; calibrated in round 1 on a kernel of known
     traffic) + WRITE_SIZE as is."""
     key = {'c2': 'c2_unit', 'c4': 'c4_unit', 'c4job': 'c4_unit'}.get(workload)
     if key is None:
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_seed_scan.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03b_pmc_seed_scan.json')) as f:
             d = json.load(f)
         return int(1024 * (2 * d[key + '_FETCH_SIZE_KB_per_launch']['k34_scan_extend'] + d[key + '_WRITE_SIZE_KB_per_launch']['k34_scan_extend']))
     except Exception:
@@ -427,7 +427,7 @@ def main():
             'roofline': {'kernel': 'k34_scan_extend (seed scan fused with the gap-free pre-filter; one launch per BATCH of (target, query, strand) units: grid.y = unit)',
                          'bound': 'valu', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                          'valu': valu_issue(t_fill * 1e3 * launches / units) if args.workload in ('c4', 'c4job') else None,
-                         'traffic': (traffic * units / launches) if traffic else None, 'traffic_unit': 'HBM bytes per launch = per-unit bytes x units per launch (rocprofv3 PMC on one C4 unit, profiles/r03_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
+                         'traffic': (traffic * units / launches) if traffic else None, 'traffic_unit': 'HBM bytes per launch = per-unit bytes x units per launch (rocprofv3 PMC on one C4 unit, profiles/r03b_pmc_seed_scan.json; FETCH_SIZE doubled per the guide)',
                          'traffic_frac': (traffic * units / launches / t_fill / 8e12) if (traffic and t_fill > 0) else None,
                          'kernel_bytes_per_launch': agg['scan_bytes_kernel'] / launches,
                          'algorithmic_bytes_per_launch': b_alg, 'avg_launch_ms': t_fill * 1e3, 'launches_timed_rank0': int(launches),

@@ -3,10 +3,10 @@
 # FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one pass), kernel-trace only.  FETCH_SIZE counts
 # 64-byte requests where wide coalesced reads issue 128-byte ones on gfx950 (MI355X_MICROARCH.md, HBM): doubled in
 # the summary, WRITE_SIZE taken as is.  The split pass of K34 (a launch that finds no listed tile on these units) is left out of
-# the average.  -> gpurun_out/r03_pmc_seed_scan.json
+# the average.  -> gpurun_out/${TAG:-r03b}_pmc_seed_scan.json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r03_pmc_seed_scan.json
+OUT=$R/gpurun_out/${TAG:-r03b}_pmc_seed_scan.json
 echo "{" > $OUT
 first=1
 for unit in "c4_unit 1e7 1000" "c2_unit 5e6 50"; do
