@@ -1,12 +1,13 @@
-"""K34's multi-segment branch under independent checks (reference call site src/mimeo/wrappers.py:1025-1037).
+"""K34's tiles of several LDS segments under independent checks (reference call site src/mimeo/wrappers.py:1025-1037).
 
-A first-pass tile of K34 holds Lq / 4096 query entries: scaffolds of up to 5 Mbp fit one LDS segment (the `single`
-branch of k34_fused.hip), a 10 Mbp C4 scaffold is two segments and a 20 Mbp super-scaffold four — the clipped
-neighbour ranges, the descriptor clipping at a round's edge and the prefetch wrap from a segment's last target
-chunk to the next segment's first only run there.  These tests put exactly those shapes under (a) the C oracle, at
-sizes it finishes in seconds (its cost goes with Lt x Lq), and (b) the round-1 decomposition of the same stage
-(MIMEO_HEAVY=v1: stand-alone seed scan K3 + hit array + K4 fast kernel), byte for byte, at C2 / C4 unit size; the
-packed path's four-segment super-scaffolds are compared with the unit-per-pair path on the whole C2 job."""
+A first-pass tile of K34 holds Lq / 4096 query entries: scaffolds of up to 5 Mbp fit one LDS segment of 1280 entries, a 10 Mbp C4
+scaffold is two segments — cut at the middle key when both halves fit (a chunk then takes 12 probes or 1), else by entry count —
+and a 20 Mbp super-scaffold four.  The offsets clamped to a segment, the probes a chunk may skip, the ring of pair descriptors
+that runs across a segment's chunks and the prefetch wrap from a segment's last target chunk to the next segment's first only
+show at those sizes.  These tests put exactly those shapes under (a) the C oracle, at sizes it finishes in seconds (its cost
+goes with Lt x Lq), and (b) the round-1 decomposition of the same stage (MIMEO_HEAVY=v1: stand-alone seed scan K3 + hit array
++ K4 fast kernel) and the other forms of the first pass (MIMEO_K34_FORM), byte for byte, at C2 / C4 unit size; the packed
+path's four-segment super-scaffolds are compared with the unit-per-pair path on the whole C2 job."""
 import hashlib
 
 import numpy as np
