@@ -13,8 +13,10 @@
 //     of QSEG entries, and each wavefront keeps the frames of 64 target entries in registers (one entry per lane,
 //     the next chunk's already in flight);
 //   * a wavefront enumerates the (target entry, query entry) pairs of its chunk into a small LDS queue of
-//     descriptors (prefix sum of the per-entry counts: full wavefronts whatever the per-entry fan-out, which is
-//     Poisson(7.8) on a C4 unit); a lane takes one pair, fetches the target frame from its owner lane
+//     descriptors — first pass: probe by probe and level by level (a ballot and v_mbcnt per level) into a ring of 128;
+//     split pass: lane-major behind a prefix sum of the per-entry counts, long ranges densely — so that the rounds are
+//     full wavefronts whatever the per-entry fan-out, which is Poisson(7.8) on a C4 unit; a lane takes one pair, fetches
+//     the target frame from its owner lane
 //     (ds_bpermute) and the query frame from LDS, and runs the pre-filter: twelve XORs bring the two frames
 //     together, every shift of the popcount bounds and of the earlier-seed-hit test is a compile-time constant;
 //   * the ~4 % of the pairs the filter cannot dismiss go, compacted per wavefront (ballot + prefix count), to the
