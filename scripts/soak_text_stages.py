@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak (build container only: needs /root/reference, bash, awk, sed, sort): the host text stages A11 / A12 / A16 of
-mimeo_amd.formats against the REFERENCE'S OWN pipeline on random inputs.
+mimeo_amd.formats (A11 / A12 / A14 / A16) against the REFERENCE'S OWN pipeline on random inputs.
 
     python scripts/soak_text_stages.py [cases] [first seed]
 
@@ -10,7 +10,8 @@ used touches it) make the command list, and the reference's own run_cmd runs it 
 prepared synthetic --format=general file to --output= (LASTZ is absent; the alignment arithmetic is not what is tested here) — up to
 the first bedtools line (bedtools is absent).  The TAB (and the _intra TAB of --strictSelf) and the sorted BED must equal what
 formats.tab_block / formats.bed_intervals make of the same records; import_Align + writeGFFlines (pandas) must equal
-formats.import_align + gff_map_lines.  Random thresholds, names that sort differently in C and in Python order, identities on
+formats.import_align + gff_map_lines; the reference's GFF3 formatter (its last two commands: header echo + the minLen / awk line, A14) run on a
+random merged BED must equal formats.gff_repeat_lines.  Random thresholds, names that sort differently in C and in Python order, identities on
 and next to the printed-tenth boundaries."""
 import os
 import random
@@ -95,7 +96,7 @@ def one(U, W, seed, work, fake):
     cut = next((i for i, c in enumerate(cmds) if 'genomecov' in c), len(cmds))
     tmpd = MG.run_reference_cmds(U, cmds[:cut], wd)
     bad = []
-    stats = {'tab_rows': 0, 'bed_rows': 0, 'map_gff_lines': 0}
+    stats = {'tab_rows': 0, 'bed_rows': 0, 'map_gff_lines': 0, 'gff_lines': 0}
     main, intra = [formats.TAB_HEADER], [formats.TAB_HEADER]
     for a in names:
         for b in names:
@@ -136,6 +137,36 @@ def one(U, W, seed, work, fake):
                 bad.append('map_gff')
         except SystemExit:
             pass   # the reference exits on an empty table; formats.import_align does too (tests/test_host_formats.py)
+    if mode in ('self', 'x') and not strict:   # (--strictSelf writes its header earlier and two sections: workflow tests)
+        # A14: the reference's last two commands (GFF header + the minLen / awk formatter) on a random merged BED
+        tail = cmds[-2:]
+        assert 'gff-version' in tail[0] and 'sprintf' in tail[1]
+        cnames = sorted(names, key=lambda s: s.encode())
+        regs = []
+        for c in cnames:
+            pos = 0
+            for _ in range(rng.randint(0, 12)):
+                pos += rng.randint(1, 5000)
+                ln = rng.choice([1, 50, minLen - 1, minLen, minLen + 1, 1000, rng.randint(1, 30000)])
+                regs.append((c, pos, pos + ln))
+                pos += ln
+        cwd = os.getcwd()
+        os.chdir(wd)
+        try:
+            with open('temp.bed', 'w') as f:
+                f.write(''.join('%s\t%d\t%d\n' % r for r in regs))
+            with open('tail.sh', 'w') as f:
+                f.write('\n'.join(tail) + '\n')
+            U.syscall('bash tail.sh')
+        finally:
+            os.chdir(cwd)
+        exp = open(outgff).read()
+        kept = np.array([(cnames.index(c), a, b) for c, a, b in regs if b - a >= minLen], dtype=_ffi.INTERVAL)
+        src, label, prefix = ('mimeo-self', 'Self_Repeat', 'Self_Repeat') if mode == 'self' else ('mimeo', 'B_Repeat', 'B_Repeat')
+        got = formats.GFF_HEADER + '\n' + ''.join(l + '\n' for l in formats.gff_repeat_lines(kept, cnames, src, label, prefix))
+        stats['gff_lines'] = exp.count('\n')
+        if got != exp:
+            bad.append('gff')
     shutil.rmtree(wd, ignore_errors=True)
     return bad, mode, strict, stats
 
