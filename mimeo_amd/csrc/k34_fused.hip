@@ -61,7 +61,9 @@ struct FusedArgs {
     ExtQueues q;
     HeavyPlan plan;
     int xdrop, hspthresh, transitions;
-    uint32_t dbg;  // development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on
+    uint32_t dbg;  // switch word.  Development (MIMEO_K34_DEBUG): 1 = no pre-filter arithmetic, 2 = nothing is passed on, 4 = no pair
+                   // rounds, 8 = no descriptors either (lane-major emission), 16 = run members are not dropped; bits 5 and 6 (32, 64) =
+                   // the form of the first pass (MIMEO_K34_FORM, k4_extend.hip)
 };
 
 // ---- pre-filter on two frames in the common alignment ------------------------------------------------------
