@@ -897,6 +897,10 @@ int ExtBatch::start(const std::vector<UnitWork> &work, const mimeo_params *p, co
         // (0) or by entry count (32); descriptors written level by level (0) or lane-major behind a prefix sum (64).
         // MIMEO_K34_FORM = level (0) | cut (32) | half (64) | lane (96: the round-2/3 form) picks one (tests, scripts/gpu_k34_ab.py).
         const char *form = getenv("MIMEO_K34_FORM");
+        if (form && strcmp(form, "level") && strcmp(form, "cut") && strcmp(form, "half") && strcmp(form, "lane")) {
+            set_error(std::string("MIMEO_K34_FORM=") + form + ": not one of level, cut, half, lane");
+            return MIMEO_ERR_ARG;
+        }
         const uint32_t bits = !form ? K34_FORM_DEFAULT : !strcmp(form, "level") ? 0u : !strcmp(form, "cut") ? 32u : !strcmp(form, "half") ? 64u : 96u;
         k34_dbg_ = (k34_dbg_ & ~96u) | bits;
     }
