@@ -43,6 +43,27 @@ def test_bench_rows_are_dealt_round_robin_and_cover_the_job():
     assert [bench.row_of(k, 1, 0, 6) for k in range(6)] == [bench.row_of(k // 2, 2, k % 2, 6) for k in range(6)]
 
 
+def test_bench_roofline_blocks_read_the_committed_counter_files(monkeypatch):
+    """bench.py prices K34's launch with counters kept under profiles/ (SQ_INSTS_VALU, the ISA opcode mix, FETCH / WRITE_SIZE): the
+    files the shipped form needs must be there and make sense — a missing one would turn `roofline.valu` into an error string on the
+    GPU box.  0.905 ms per C4 unit is the measured launch time of the default form, 0.974 that of the lane-major form."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv('MIMEO_K34_FORM', raising=False)
+    v = bench.valu_issue(0.905)
+    assert 'error' not in v and 4.0e8 < v['insts_per_launch'] < 5.0e8 and 3.5 < v['cycles_per_inst_mix'] < 4.0
+    assert 0.7 < v['frac_of_issue_peak'] < 0.85 and 'r03b_pmc_k34_sq.json' in v['source']
+    monkeypatch.setenv('MIMEO_K34_FORM', 'lane')
+    w = bench.valu_issue(0.974)
+    assert 'error' not in w and w['insts_per_launch'] > v['insts_per_launch'] and 0.75 < w['frac_of_issue_peak'] < 0.9
+    monkeypatch.setenv('MIMEO_K34_FORM', 'cut')
+    assert 'error' in bench.valu_issue(0.9)      # no counters on file for that form: said, not guessed
+    for wl in ('c4', 'c2'):
+        t = bench.pmc_traffic(wl)
+        assert isinstance(t, int) and 3e8 < t < 3e9
+    assert bench.pmc_traffic('c3') is None
+
+
 def test_bench_a11_filter_matches_the_printed_identity_rule():
     """The vectorised A11 filter of bench.py keeps exactly the records formats.tab_block keeps
     (length1 >= minLen and the PRINTED one-decimal identity >= minIdt, wrappers.py:1043-1052)."""
