@@ -92,3 +92,34 @@ def test_chain_stage_of_the_c_oracle_against_the_rule_spelled_out():
             k = pred[k]
         assert np.array_equal(got['tstart'], s['tstart']) and np.array_equal(got['length'], s['length'])
         assert np.array_equal(got['flags'] & 1, flags), (n, span, equal)
+
+
+def test_collapse_is_the_four_commands_one_after_the_other():
+    """The collapse oracle (per-base depth, maximal runs >= minCov, minLen) against the reference's four commands taken literally
+    (src/mimeo/wrappers.py:1131-1177): `bedtools genomecov -bg` (runs of equal depth > 0: oracle's genomecov_bg) | awk '$4 >= cov' |
+    sort | `bedtools merge` (overlapping and book-ended rows become one: documented default -d 0) | awk '$3 - $2 >= minLen', on random
+    interval sets with ends beyond the chromosome, empty chromosomes and stacks of identical intervals.  Both sides state bedtools'
+    documented semantics (bedtools is absent: hand-derived, like collapse_kat.json); what this pins is that the one-pass restatement
+    K7 is held to equals the literal pipeline."""
+    import random
+    rng = random.Random(7)
+    for case in range(200):
+        chromlens = {c: rng.choice([50, 400, 3000]) for c in ('s1', 's10', 's2', 'Z')}
+        iv = []
+        for _ in range(rng.randint(0, 60)):
+            c = rng.choice(list(chromlens))
+            s = rng.randint(0, chromlens[c] + 20)
+            e = s + rng.choice([0, 1, 5, 40, 300, 5000])
+            iv += [(c, s, e)] * rng.choice([1, 1, 1, 2, 4])
+        min_cov, min_len = rng.choice([1, 2, 3, 5]), rng.choice([1, 10, 100])
+        got = P.coverage_collapse(iv, chromlens, min_cov, min_len)
+        rows = [r for r in P.genomecov_bg(iv, chromlens) if r[3] >= min_cov]              # genomecov -bg | awk '$4 >= cov'
+        rows.sort(key=lambda r: (r[0].encode(), r[1], r[2]))                                # sort -k 1,1 -k 2n,3n (LC_ALL=C)
+        merged = []
+        for c, s, e, _ in rows:                                                             # bedtools merge
+            if merged and merged[-1][0] == c and s <= merged[-1][2]:
+                merged[-1][2] = max(merged[-1][2], e)
+            else:
+                merged.append([c, s, e])
+        exp = [(c, s, e) for c, s, e in merged if e - s >= min_len]                         # awk '$3 - $2 >= minLen'
+        assert got == exp, (case, min_cov, min_len)
